@@ -1,0 +1,157 @@
+/*
+ * include/rt_hip.h -- C ABI of the MI355X (gfx950) trace path.
+ *
+ * This is the drop-in boundary for the per-pixel trace path of Copper280z/raytrace: what a cgo-style
+ * `extern fn` block in Zig binds (see INTEGRATION.md for the shim).  Plain pointers and sizes only.
+ * Every entry point names the reference interface it replaces (paths under /root/reference/src).
+ *
+ * Conventions
+ *   - return value: 0 = RT_OK, negative = error (rt_strerror); nothing throws or aborts across the ABI
+ *     (the reference propagates Zig error unions with `try`, raytracer.zig:517,580).
+ *   - the caller owns every host pointer for the duration of the call only; the library copies.
+ *   - device memory is owned by the opaque rt_ctx (one per GPU; not thread-safe per ctx).
+ *   - image layout: index jr*nx+i, top row first (raytracer.zig:521-528), 3 channels interleaved.
+ *   - material kinds: 0 lambertian, 1 metal, 2 dielectric (raytracer.zig:402-406).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_E_ARG = -1,    /* bad argument */
+    RT_E_HIP = -2,    /* a HIP runtime call failed (rt_last_hip_error) */
+    RT_E_NOMEM = -3,
+    RT_E_STATE = -4,  /* e.g. render before upload */
+    RT_E_IO = -5,
+    RT_E_CAP = -6     /* output capacity too small */
+};
+
+enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
+
+typedef struct rt_ctx rt_ctx;
+
+/* camera.zig:9-14 BasicCamera / :20-24 MovableCamera: four vectors.  subtract_origin = 1 selects
+ * MovableCamera.get_ray (camera.zig:39), 0 BasicCamera.get_ray (camera.zig:16).  Replaces the implicit
+ * global `pub var cam` (raytracer.zig:710). */
+typedef struct {
+    float    lower_left[3], horizontal[3], vertical[3], origin[3];
+    uint32_t subtract_origin;
+} rt_camera;
+
+/* SoA view of `world.objects: []const Sphere` (raytracer.zig:38-41, :712) with the Material union
+ * (raytracer.zig:402-449) flattened: rgb = albedo|color, param = roughness|index.  Also used as the
+ * material table of a triangle scene (then only kind/r/g/b/param are read). */
+typedef struct {
+    uint32_t        n;
+    const float    *cx, *cy, *cz, *radius;   /* radius may be negative (raytracer.zig:677) */
+    const uint32_t *kind;
+    const float    *r, *g, *b, *param;
+} rt_spheres;
+
+/* Triangle soup (build-defined: the reference has no ray-triangle code; the meshes are the
+ * zmesh parametric spheres of main.zig:128-138).  v0/v1/v2 are [n][3] floats. */
+typedef struct {
+    uint32_t        n;
+    const float    *v0, *v1, *v2;
+    const uint32_t *material;                /* index into the material table */
+} rt_triangles;
+
+/* Everything that is a compile-time constant in the reference ("Config / flags"). */
+typedef struct {
+    uint32_t nx, ny;                 /* shape_s, raytracer.zig:26-29 */
+    uint32_t spp_begin, spp_end;     /* global sample indices rendered by this call: [begin, end) */
+    uint32_t spp_total;              /* divisor of the mean (num_samples, raytracer.zig:542) */
+    uint32_t max_depth;              /* reference: 16 (raytracer.zig:556) */
+    float    t_min;                  /* reference: 0.001 (raytracer.zig:555) */
+    uint64_t seed;                   /* counter-RNG key (the reference seeds sfc64 with i*123, :600) */
+    uint32_t tile_x0, tile_y0, tile_x1, tile_y1;  /* output rect [x0,x1) x [y0,y1); all 0 = whole image */
+    uint32_t row_offset_q3;          /* 1: j = ny - jr as raytracer.zig:523; 0: j = ny-1-jr */
+    uint32_t spp_chunk;              /* 0: one running sum per pixel (bit-matches the oracle's order);
+                                        >0: samples summed in chunks of this size (more parallel work items) */
+} rt_config;
+
+typedef struct {
+    uint64_t rays;                   /* world.hit evaluations (primary + scattered) */
+    uint64_t primary_rays;
+    double   kernel_ms;              /* hipEvent time of the trace kernel(s) */
+    uint64_t rays_by_depth[20];      /* filled only when RT_FLAG_DEPTH_HISTOGRAM is set */
+} rt_stats;
+
+enum { RT_FLAG_DEPTH_HISTOGRAM = 1u };
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Replaces nothing in the reference (its path is pure CPU); mirrors compute.zig:19-29 Compute.create. */
+int  rt_create(int device, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_strerror(int code);
+int  rt_last_hip_error(const rt_ctx *ctx);   /* hipError_t of the last failing HIP call */
+int  rt_set_flags(rt_ctx *ctx, uint32_t flags);
+
+/* ---- scene upload: the `world: Hittable` argument of Render (raytracer.zig:517) ------------- */
+/* spheres and/or triangles; `materials` is required when triangles are given. */
+int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *triangles,
+                    const rt_spheres *materials);
+
+/* ---- the trace path --------------------------------------------------------------------------
+ * rt_render replaces the fan-out + join + average of render_and_write (raytracer.zig:588-617), i.e.
+ * every Render/trace/color call (raytracer.zig:517-572), and returns host images:
+ *   accum_mean [ny*nx*3] f32  linear mean radiance, sum over [spp_begin,spp_end) / spp_total
+ *   rgb8       [ny*nx*3] u8   trunc(255.99*sqrt(mean)) (raytracer.zig:527,545-549)
+ *   raycount   [ny*nx]   u32  world.hit evaluations per pixel (parity aid)
+ * any of which may be NULL.  Blocking, like the reference call. */
+int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
+              float *accum_mean, uint8_t *rgb8, uint32_t *raycount, rt_stats *stats);
+
+/* Device-resident variant: ADDS the radiance sum of samples [spp_begin,spp_end) into the caller's
+ * device buffer d_accum_sum [ny*nx*3] f32 (and ray counts into d_raycount [ny*nx] u32 if non-NULL) on
+ * `stream` (a hipStream_t; NULL = the ctx's own stream).  If stats != NULL the call synchronises the
+ * stream and fills it; otherwise it only enqueues. */
+int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
+                     float *d_accum_sum, uint32_t *d_raycount, void *stream, rt_stats *stats);
+
+/* Device tonemap: mean = sum / spp_total; rgb8 = trunc(255.99*sqrt(mean)) (raytracer.zig:527,542-549).
+ * d_mean and d_rgb8 may each be NULL; d_mean may alias d_accum_sum. */
+int rt_tonemap_device(rt_ctx *ctx, const float *d_accum_sum, uint32_t n_pixels, uint32_t spp_total,
+                      float *d_mean, uint8_t *d_rgb8, void *stream);
+
+/* ---- host-side mirrors of the reference API (no GPU needed) ---------------------------------- */
+/* camera.zig:9-14 */
+void rt_camera_basic(rt_camera *cam);
+/* MovableCamera.SetPosition, camera.zig:25-37 */
+void rt_camera_set_position(rt_camera *cam, const float lookfrom[3], const float lookat[3],
+                            const float v_up[3], float vfov_deg, float aspect);
+/* Random_Scene, raytracer.zig:644-689 (sphere list; sfc64 stream seeded with `seed`, reference 0).
+ * Writes up to cap spheres into the SoA arrays; returns the sphere count or RT_E_CAP. */
+int rt_random_scene(uint32_t half_size, uint64_t seed, uint32_t cap,
+                    float *cx, float *cy, float *cz, float *radius, uint32_t *kind,
+                    float *r, float *g, float *b, float *param);
+/* book_segments.zig:146-149,162: sphere (0,0,-1) r .5 + ground (0,-100.5,-1) r 100, lambertian .5 */
+int rt_two_sphere_scene(uint32_t cap, float *cx, float *cy, float *cz, float *radius, uint32_t *kind,
+                        float *r, float *g, float *b, float *param);
+/* zmesh.Shape.initParametricSphere + scale + unweld as used at main.zig:128-143.  slices/stacks <= 0
+ * selects the reference's per-radius tessellation.  v0/v1/v2 are [cap][3].  Returns the triangle
+ * count or RT_E_CAP; call with cap = 0 to query the count. */
+int rt_tessellate_spheres(const rt_spheres *spheres, int slices, int stacks, uint32_t cap,
+                          float *v0, float *v1, float *v2, uint32_t *material);
+/* write_ppm_image, image.zig:18-37 (ASCII P3) */
+int rt_write_ppm(const char *fname, const uint8_t *rgb8, uint32_t nx, uint32_t ny);
+/* render_and_write, raytracer.zig:580-633: render all of cfg on the ctx's GPU and write the PPM. */
+int rt_render_and_write(rt_ctx *ctx, const char *fname, const rt_camera *cam, const rt_config *cfg,
+                        rt_stats *stats);
+
+/* ---- device self-test (parity aid): evaluates the device's IEEE div/sqrt, cbrt, Philox and
+ * u32->float on n inputs so tests can compare them bit-for-bit with the host.  All arrays are host
+ * pointers of n elements (philox_out: 4n). */
+int rt_selftest_math(rt_ctx *ctx, uint32_t n, const float *a, const float *b,
+                     float *out_div, float *out_sqrt, float *out_cbrt,
+                     const uint32_t *ctr0, uint32_t *philox_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""ctypes loader for the C-ABI library (include/rt_hip.h).
+
+The library is built in-tree (raytrace_amd/librt_hip.so) by `make -C raytrace_amd/csrc` /
+__graft_entry__.build().  There is no fallback: if it is missing, importing the product path fails.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
+RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2
+RT_FLAG_DEPTH_HISTOGRAM = 1
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("origin", C.c_float * 3), ("subtract_origin", C.c_uint32)]
+
+
+class rt_spheres(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("cx", f32p), ("cy", f32p), ("cz", f32p), ("radius", f32p),
+                ("kind", u32p), ("r", f32p), ("g", f32p), ("b", f32p), ("param", f32p)]
+
+
+class rt_triangles(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("v0", f32p), ("v1", f32p), ("v2", f32p), ("material", u32p)]
+
+
+class rt_config(C.Structure):
+    _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("spp_begin", C.c_uint32), ("spp_end", C.c_uint32),
+                ("spp_total", C.c_uint32), ("max_depth", C.c_uint32), ("t_min", C.c_float), ("seed", C.c_uint64),
+                ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32), ("tile_x1", C.c_uint32), ("tile_y1", C.c_uint32),
+                ("row_offset_q3", C.c_uint32), ("spp_chunk", C.c_uint32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("kernel_ms", C.c_double),
+                ("rays_by_depth", C.c_uint64 * 20)]
+
+
+# every symbol include/rt_hip.h declares
+SYMBOLS = [
+    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
+    "rt_render", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
+    "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
+    "rt_selftest_math",
+]
+
+_lib = None
+
+
+def load():
+    """Load librt_hip.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "raytrace_amd: %s is missing -- build it with `make -C raytrace_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_create.restype = C.c_int
+    L.rt_destroy.argtypes = [vp]
+    L.rt_destroy.restype = None
+    L.rt_strerror.argtypes = [C.c_int]
+    L.rt_strerror.restype = C.c_char_p
+    L.rt_last_hip_error.argtypes = [vp]
+    L.rt_last_hip_error.restype = C.c_int
+    L.rt_set_flags.argtypes = [vp, C.c_uint32]
+    L.rt_set_flags.restype = C.c_int
+    L.rt_upload_scene.argtypes = [vp, C.POINTER(rt_spheres), C.POINTER(rt_triangles), C.POINTER(rt_spheres)]
+    L.rt_upload_scene.restype = C.c_int
+    L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
+    L.rt_render.restype = C.c_int
+    L.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
+    L.rt_render_device.restype = C.c_int
+    L.rt_tonemap_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rt_tonemap_device.restype = C.c_int
+    L.rt_camera_basic.argtypes = [C.POINTER(rt_camera)]
+    L.rt_camera_basic.restype = None
+    L.rt_camera_set_position.argtypes = [C.POINTER(rt_camera), C.c_float * 3, C.c_float * 3, C.c_float * 3,
+                                         C.c_float, C.c_float]
+    L.rt_camera_set_position.restype = None
+    L.rt_random_scene.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32] + [vp] * 9
+    L.rt_random_scene.restype = C.c_int
+    L.rt_two_sphere_scene.argtypes = [C.c_uint32] + [vp] * 9
+    L.rt_two_sphere_scene.restype = C.c_int
+    L.rt_tessellate_spheres.argtypes = [C.POINTER(rt_spheres), C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
+    L.rt_tessellate_spheres.restype = C.c_int
+    L.rt_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.rt_write_ppm.restype = C.c_int
+    L.rt_render_and_write.argtypes = [vp, C.c_char_p, C.POINTER(rt_camera), C.POINTER(rt_config), C.POINTER(rt_stats)]
+    L.rt_render_and_write.restype = C.c_int
+    L.rt_selftest_math.argtypes = [vp, C.c_uint32] + [vp] * 7
+    L.rt_selftest_math.restype = C.c_int
+    _lib = L
+    return L
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, where, hip=0):
+        self.code = code
+        self.hip = hip
+        msg = load().rt_strerror(code).decode()
+        super().__init__("%s: %s (code %d, hip %d)" % (where, msg, code, hip))

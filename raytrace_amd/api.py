@@ -1,0 +1,301 @@
+"""Python host mirror of the reference's camera / scene / render API over the C ABI.
+
+Names follow the reference: MovableCamera.SetPosition (camera.zig:25), Random_Scene
+(raytracer.zig:644), render_and_write (raytracer.zig:580), write_ppm_image (image.zig:18).
+All rendering goes through librt_hip.so; there is no CPU path in this package.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import RtError, rt_camera, rt_config, rt_spheres, rt_stats
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+class Spheres:
+    """SoA view of `world.objects` (raytracer.zig:38-41 Sphere + :402-449 Material)."""
+
+    FIELDS = ("cx", "cy", "cz", "radius", "kind", "r", "g", "b", "param")
+
+    def __init__(self, cx, cy, cz, radius, kind, r, g, b, param):
+        self.cx, self.cy, self.cz, self.radius = _f32(cx), _f32(cy), _f32(cz), _f32(radius)
+        self.kind = np.ascontiguousarray(kind, dtype=np.uint32)
+        self.r, self.g, self.b, self.param = _f32(r), _f32(g), _f32(b), _f32(param)
+        n = len(self.cx)
+        for f in self.FIELDS:
+            if len(getattr(self, f)) != n:
+                raise ValueError("Spheres: field %s has length %d, expected %d" % (f, len(getattr(self, f)), n))
+
+    def __len__(self):
+        return len(self.cx)
+
+    @classmethod
+    def empty(cls, n):
+        z = np.zeros(n, dtype=np.float32)
+        return cls(z.copy(), z.copy(), z.copy(), z.copy(), np.zeros(n, np.uint32), z.copy(), z.copy(), z.copy(), z.copy())
+
+    def view(self):
+        return rt_spheres(len(self), _ptr(self.cx, _lib.f32p), _ptr(self.cy, _lib.f32p), _ptr(self.cz, _lib.f32p),
+                          _ptr(self.radius, _lib.f32p), _ptr(self.kind, _lib.u32p), _ptr(self.r, _lib.f32p),
+                          _ptr(self.g, _lib.f32p), _ptr(self.b, _lib.f32p), _ptr(self.param, _lib.f32p))
+
+    def _out_ptrs(self):
+        return [getattr(self, f).ctypes.data for f in self.FIELDS]
+
+    def take(self, n):
+        return Spheres(*[getattr(self, f)[:n].copy() for f in self.FIELDS])
+
+
+def Random_Scene(half_size=11, seed=0):
+    """Random_Scene (raytracer.zig:644-689) with std.Random.Sfc64 seeded `seed` (reference: 0, :732)."""
+    cap = 2 * (2 * half_size) ** 2 + 8
+    s = Spheres.empty(cap)
+    n = _lib.load().rt_random_scene(half_size, seed, cap, *s._out_ptrs())
+    if n < 0:
+        raise RtError(n, "rt_random_scene")
+    return s.take(n)
+
+
+def Two_Sphere_Scene():
+    """book_segments.zig:146-149,162."""
+    s = Spheres.empty(2)
+    n = _lib.load().rt_two_sphere_scene(2, *s._out_ptrs())
+    if n < 0:
+        raise RtError(n, "rt_two_sphere_scene")
+    return s.take(n)
+
+
+class Triangles:
+    """Triangle soup + the material table it indexes (build-defined; main.zig:115-154 meshes)."""
+
+    def __init__(self, v0, v1, v2, material):
+        self.v0, self.v1, self.v2 = _f32(v0).reshape(-1, 3), _f32(v1).reshape(-1, 3), _f32(v2).reshape(-1, 3)
+        self.material = np.ascontiguousarray(material, dtype=np.uint32)
+
+    def __len__(self):
+        return len(self.material)
+
+    def view(self):
+        return _lib.rt_triangles(len(self), _ptr(self.v0, _lib.f32p), _ptr(self.v1, _lib.f32p),
+                                 _ptr(self.v2, _lib.f32p), _ptr(self.material, _lib.u32p))
+
+
+def Tessellate_Spheres(spheres, slices=0, stacks=0):
+    """zmesh parametric spheres as placed at main.zig:128-143; (0,0) = the reference's per-radius choice."""
+    L = _lib.load()
+    sv = spheres.view()
+    n = L.rt_tessellate_spheres(C.byref(sv), slices, stacks, 0, None, None, None, None)
+    if n < 0:
+        raise RtError(n, "rt_tessellate_spheres")
+    v0 = np.zeros((n, 3), np.float32)
+    v1 = np.zeros((n, 3), np.float32)
+    v2 = np.zeros((n, 3), np.float32)
+    mat = np.zeros(n, np.uint32)
+    m = L.rt_tessellate_spheres(C.byref(sv), slices, stacks, n, v0.ctypes.data, v1.ctypes.data, v2.ctypes.data,
+                                mat.ctypes.data)
+    if m != n:
+        raise RtError(m if m < 0 else _lib.RT_E_CAP, "rt_tessellate_spheres")
+    return Triangles(v0, v1, v2, mat)
+
+
+class _CameraBase:
+    def __init__(self):
+        self._c = rt_camera()
+
+    @property
+    def lower_left(self):
+        return np.array(self._c.lower_left, dtype=np.float32)
+
+    @property
+    def horizontal(self):
+        return np.array(self._c.horizontal, dtype=np.float32)
+
+    @property
+    def vertical(self):
+        return np.array(self._c.vertical, dtype=np.float32)
+
+    @property
+    def origin(self):
+        return np.array(self._c.origin, dtype=np.float32)
+
+    def as_array(self):
+        return np.stack([self.lower_left, self.horizontal, self.vertical, self.origin])
+
+    def to_abi(self):
+        return self._c
+
+
+class BasicCamera(_CameraBase):
+    """camera.zig:9-19."""
+
+    def __init__(self):
+        super().__init__()
+        _lib.load().rt_camera_basic(C.byref(self._c))
+
+
+class MovableCamera(_CameraBase):
+    """camera.zig:20-42; defaults equal BasicCamera's vectors until SetPosition is called."""
+
+    def __init__(self):
+        super().__init__()
+        _lib.load().rt_camera_basic(C.byref(self._c))
+        self._c.subtract_origin = 1
+
+    def SetPosition(self, lookfrom, lookat, v_up, vfov, aspect):
+        a3 = C.c_float * 3
+        _lib.load().rt_camera_set_position(C.byref(self._c), a3(*map(float, lookfrom)), a3(*map(float, lookat)),
+                                           a3(*map(float, v_up)), C.c_float(vfov), C.c_float(aspect))
+        return self
+
+
+def book_camera(nx, ny):
+    """raytracer.zig:731 / main.zig:569: (13,2,3.5) -> (0,0,0), vfov 20, aspect f32(nx)/f32(ny)."""
+    return MovableCamera().SetPosition((13.0, 2.0, 3.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0,
+                                       float(np.float32(nx) / np.float32(ny)))
+
+
+def make_config(nx, ny, spp, max_depth=16, seed=1, t_min=0.001, spp_begin=0, spp_end=None, spp_total=None,
+                tile=None, row_offset_q3=1, spp_chunk=0):
+    """rt_config with the reference's constants as defaults (raytracer.zig:555-556)."""
+    if spp_end is None:
+        spp_end = spp
+    if spp_total is None:
+        spp_total = spp
+    x0, y0, x1, y1 = tile if tile is not None else (0, 0, 0, 0)
+    return rt_config(nx, ny, spp_begin, spp_end, spp_total, max_depth, t_min, seed, x0, y0, x1, y1,
+                     row_offset_q3, spp_chunk)
+
+
+@dataclass
+class RenderResult:
+    accum: np.ndarray      # [ny*nx, 3] f32 linear mean radiance
+    rgb8: np.ndarray       # [ny*nx, 3] u8
+    raycount: np.ndarray   # [ny*nx] u32 (None unless requested)
+    rays: int
+    primary_rays: int
+    kernel_ms: float
+    rays_by_depth: list
+
+
+def _stats_tuple(st):
+    return int(st.rays), int(st.primary_rays), float(st.kernel_ms), [int(v) for v in st.rays_by_depth]
+
+
+class Context:
+    """One GPU's render context (rt_ctx).  Mirrors compute.zig's create -> upload -> dispatch -> readback."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.rt_create(device, C.byref(h))
+        if rc != 0:
+            raise RtError(rc, "rt_create")
+        self._h = h
+        self.device = device
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise RtError(rc, where, self._L.rt_last_hip_error(self._h))
+
+    def set_flags(self, flags):
+        self._check(self._L.rt_set_flags(self._h, flags), "rt_set_flags")
+
+    def upload_scene(self, spheres=None, triangles=None, materials=None):
+        sv = spheres.view() if spheres is not None else None
+        tv = triangles.view() if triangles is not None else None
+        mv = materials.view() if materials is not None else None
+        rc = self._L.rt_upload_scene(self._h, C.byref(sv) if sv is not None else None,
+                                     C.byref(tv) if tv is not None else None,
+                                     C.byref(mv) if mv is not None else None)
+        self._check(rc, "rt_upload_scene")
+
+    def render(self, cam, cfg, want_raycount=False):
+        """rt_render: host images out.  Blocking."""
+        n = cfg.nx * cfg.ny
+        accum = np.zeros((n, 3), np.float32)
+        rgb8 = np.zeros((n, 3), np.uint8)
+        rc_arr = np.zeros(n, np.uint32) if want_raycount else None
+        st = rt_stats()
+        rc = self._L.rt_render(self._h, C.byref(cam.to_abi()), C.byref(cfg), accum.ctypes.data, rgb8.ctypes.data,
+                               rc_arr.ctypes.data if want_raycount else None, C.byref(st))
+        self._check(rc, "rt_render")
+        rays, prim, ms, hist = _stats_tuple(st)
+        return RenderResult(accum, rgb8, rc_arr, rays, prim, ms, hist)
+
+    def render_device(self, cam, cfg, d_accum_sum, d_raycount=0, stream=0, want_stats=True):
+        """rt_render_device: adds into a device accumulation buffer (raw device pointers as ints)."""
+        st = rt_stats()
+        rc = self._L.rt_render_device(self._h, C.byref(cam.to_abi()), C.byref(cfg), C.c_void_p(d_accum_sum),
+                                      C.c_void_p(d_raycount) if d_raycount else None,
+                                      C.c_void_p(stream) if stream else None,
+                                      C.byref(st) if want_stats else None)
+        self._check(rc, "rt_render_device")
+        return _stats_tuple(st) if want_stats else None
+
+    def tonemap_device(self, d_accum_sum, n_pixels, spp_total, d_mean=0, d_rgb8=0, stream=0):
+        rc = self._L.rt_tonemap_device(self._h, C.c_void_p(d_accum_sum), n_pixels, spp_total,
+                                       C.c_void_p(d_mean) if d_mean else None,
+                                       C.c_void_p(d_rgb8) if d_rgb8 else None,
+                                       C.c_void_p(stream) if stream else None)
+        self._check(rc, "rt_tonemap_device")
+
+    def render_and_write(self, fname, cam, cfg):
+        st = rt_stats()
+        rc = self._L.rt_render_and_write(self._h, fname.encode(), C.byref(cam.to_abi()), C.byref(cfg), C.byref(st))
+        self._check(rc, "rt_render_and_write")
+        return _stats_tuple(st)
+
+    def selftest_math(self, a, b, ctr0):
+        a, b = _f32(a), _f32(b)
+        ctr0 = np.ascontiguousarray(ctr0, dtype=np.uint32)
+        n = len(a)
+        od, os_, oc = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        ph = np.zeros((n, 4), np.uint32)
+        rc = self._L.rt_selftest_math(self._h, n, a.ctypes.data, b.ctypes.data, od.ctypes.data, os_.ctypes.data,
+                                      oc.ctypes.data, ctr0.ctypes.data, ph.ctypes.data)
+        self._check(rc, "rt_selftest_math")
+        return od, os_, oc, ph
+
+
+def write_ppm_image(fname, rgb8, nx, ny):
+    """write_ppm_image, image.zig:18-37."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    rc = _lib.load().rt_write_ppm(fname.encode(), rgb8.ctypes.data, nx, ny)
+    if rc != 0:
+        raise RtError(rc, "rt_write_ppm")
+
+
+def render_and_write(fname, num_samples, world, shape, cam, device=0, seed=1, max_depth=16):
+    """render_and_write (raytracer.zig:580-633): `world` is a Spheres list, `shape` = (ny, nx) as shape_s,
+    `cam` replaces the reference's global `cam`.  num_samples is the total per pixel."""
+    ny, nx = shape
+    with Context(device) as ctx:
+        ctx.upload_scene(world)
+        return ctx.render_and_write(fname, cam, make_config(nx, ny, num_samples, max_depth=max_depth, seed=seed))

@@ -1,0 +1,403 @@
+// C-ABI implementation (include/rt_hip.h): context, scene upload, render entry points and the
+// host-side mirrors of the reference API.  Built with hipcc as host C++.
+//
+// There is no CPU fallback: every render entry point needs a HIP device and fails with RT_E_HIP
+// otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "../host/raytracer.hpp"
+#include "rt_kernels.h"
+
+struct rt_ctx {
+    int          device = 0;
+    int          num_cus = 0;
+    hipStream_t  stream = nullptr;
+    hipEvent_t   ev0 = nullptr, ev1 = nullptr;
+    uint32_t     flags = 0;
+    int          last_hip = 0;
+    // scene
+    float4      *d_geom = nullptr, *d_aux = nullptr, *d_albedo = nullptr;
+    uint32_t     n_sph = 0;
+    // per-render scratch owned by the ctx
+    uint32_t    *d_queue = nullptr;            // work-queue head
+    unsigned long long *d_stats = nullptr;     // RT_STATS_WORDS
+    float       *d_accum = nullptr;  size_t accum_cap = 0;     // floats
+    uint32_t    *d_raycount = nullptr; size_t raycount_cap = 0;
+    float       *d_mean = nullptr;   size_t mean_cap = 0;
+    uint8_t     *d_rgb8 = nullptr;   size_t rgb8_cap = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) {                             \
+            if (ctx) (ctx)->last_hip = (int)e__;             \
+            return e__ == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_HIP; \
+        }                                                    \
+    } while (0)
+
+template <typename T>
+int ensure(rt_ctx *ctx, T *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap) return RT_OK;
+    if (ptr) { HIP_TRY(ctx, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    HIP_TRY(ctx, hipMalloc((void **)&ptr, need * sizeof(T)));
+    cap = need;
+    return RT_OK;
+}
+
+int check_config(const rt_config *cfg)
+{
+    if (!cfg || cfg->nx == 0 || cfg->ny == 0) return RT_E_ARG;
+    if ((uint64_t)cfg->nx * cfg->ny > 0x7FFFFFFFull / 3) return RT_E_ARG;   // pixel index and 3*pix fit 32 bits
+    if (cfg->nx >= (1u << 24) || cfg->ny >= (1u << 24)) return RT_E_ARG;     // f32(i), f32(j) exact
+    if (cfg->spp_end < cfg->spp_begin || cfg->spp_total == 0) return RT_E_ARG;
+    if (cfg->max_depth > 1000000u) return RT_E_ARG;
+    const bool whole = !cfg->tile_x0 && !cfg->tile_y0 && !cfg->tile_x1 && !cfg->tile_y1;
+    if (!whole) {
+        if (cfg->tile_x0 >= cfg->tile_x1 || cfg->tile_y0 >= cfg->tile_y1) return RT_E_ARG;
+        if (cfg->tile_x1 > cfg->nx || cfg->tile_y1 > cfg->ny) return RT_E_ARG;
+    }
+    if (cfg->spp_chunk != 0) return RT_E_ARG;   // chunked summation is not built yet
+    return RT_OK;
+}
+
+void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim)
+{
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; ++k) {
+        p.ll[k] = cam->lower_left[k]; p.hz[k] = cam->horizontal[k];
+        p.vt[k] = cam->vertical[k];   p.org[k] = cam->origin[k];
+    }
+    p.sub_origin = cam->subtract_origin ? 1u : 0u;
+    p.nx = cfg->nx; p.ny = cfg->ny;
+    p.spp_begin = cfg->spp_begin; p.spp_end = cfg->spp_end;
+    p.max_depth = cfg->max_depth; p.t_min = cfg->t_min;
+    p.key0 = (uint32_t)cfg->seed; p.key1 = (uint32_t)(cfg->seed >> 32);
+    const bool whole = !cfg->tile_x0 && !cfg->tile_y0 && !cfg->tile_x1 && !cfg->tile_y1;
+    p.x0 = whole ? 0 : cfg->tile_x0; p.y0 = whole ? 0 : cfg->tile_y0;
+    p.x1 = whole ? cfg->nx : cfg->tile_x1; p.y1 = whole ? cfg->ny : cfg->tile_y1;
+    p.tiles_x = (p.x1 - p.x0 + 7u) / 8u;
+    const uint32_t tiles_y = (p.y1 - p.y0 + 7u) / 8u;
+    p.n_items = p.tiles_x * tiles_y * 64u;
+    p.q3 = cfg->row_offset_q3 ? 1u : 0u;
+    p.n_prim = n_prim;
+}
+
+// enqueue one trace pass on `stream`; timing events are recorded around the kernel
+int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
+                  uint32_t *d_raycount, hipStream_t stream)
+{
+    if (ctx->n_sph == 0) return RT_E_STATE;
+    TraceParams p;
+    fill_params(p, cam, cfg, ctx->n_sph);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
+    const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
+    const int per_cu = rt_trace_spheres_blocks_per_cu(hist);
+    long long want = ((long long)p.n_items + 255) / 256;             // no more blocks than work
+    long long grid = (long long)ctx->num_cus * per_cu;
+    if (grid > want) grid = want;
+    if (grid < 1) grid = 1;
+    DeviceSpheres s{ ctx->d_geom, ctx->d_aux, ctx->d_albedo, ctx->n_sph };
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (cfg->spp_end > cfg->spp_begin)
+        HIP_TRY(ctx, rt_launch_trace_spheres(p, s, d_accum_sum, d_raycount, ctx->d_queue, ctx->d_stats, hist,
+                                             (int)grid, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    return RT_OK;
+}
+
+int read_stats(rt_ctx *ctx, hipStream_t stream, rt_stats *stats)
+{
+    unsigned long long h[RT_STATS_WORDS];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    std::memset(stats, 0, sizeof *stats);
+    stats->rays = h[0]; stats->primary_rays = h[1]; stats->kernel_ms = ms;
+    for (int k = 0; k < 20; ++k) stats->rays_by_depth[k] = h[2 + k];
+    return RT_OK;
+}
+
+void soa_out(const std::vector<rt::Sphere> &objs, float *cx, float *cy, float *cz, float *radius, uint32_t *kind,
+             float *r, float *g, float *b, float *param)
+{
+    for (size_t k = 0; k < objs.size(); ++k) {
+        const rt::Sphere &s = objs[k];
+        cx[k] = s.center.x; cy[k] = s.center.y; cz[k] = s.center.z; radius[k] = s.radius;
+        kind[k] = (uint32_t)s.material.tag;
+        r[k] = s.material.rgb.x; g[k] = s.material.rgb.y; b[k] = s.material.rgb.z; param[k] = s.material.param;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_strerror(int code)
+{
+    switch (code) {
+    case RT_OK: return "ok";
+    case RT_E_ARG: return "invalid argument";
+    case RT_E_HIP: return "HIP runtime error (see rt_last_hip_error)";
+    case RT_E_NOMEM: return "out of memory";
+    case RT_E_STATE: return "invalid state (no scene uploaded?)";
+    case RT_E_IO: return "I/O error";
+    case RT_E_CAP: return "output capacity too small";
+    default: return "unknown error";
+    }
+}
+
+int rt_create(int device, rt_ctx **out)
+{
+    if (!out) return RT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RT_E_HIP;   // no GPU: fail loudly
+    if (device < 0 || device >= ndev) return RT_E_ARG;
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_E_NOMEM;
+    ctx->device = device;
+    int rc = RT_OK;
+    do {
+        hipError_t e;
+        if ((e = hipSetDevice(device)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
+        ctx->num_cus = prop.multiProcessorCount;
+        if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
+        if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
+        if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
+        if ((e = hipMalloc((void **)&ctx->d_queue, 256)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_NOMEM; break; }
+        if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * RT_STATS_WORDS)) != hipSuccess) {
+            ctx->last_hip = e; rc = RT_E_NOMEM; break;
+        }
+    } while (0);
+    if (rc != RT_OK) { rt_destroy(ctx); return rc; }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+    (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_last_hip_error(const rt_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+int rt_set_flags(rt_ctx *ctx, uint32_t flags)
+{
+    if (!ctx) return RT_E_ARG;
+    ctx->flags = flags;
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri, const rt_spheres *materials)
+{
+    if (!ctx) return RT_E_ARG;
+    if (tri && tri->n) { (void)materials; return RT_E_ARG; }   // triangle path: not built yet
+    if (!sph || sph->n == 0) return RT_E_ARG;
+    if (!sph->cx || !sph->cy || !sph->cz || !sph->radius || !sph->kind || !sph->r || !sph->g || !sph->b || !sph->param)
+        return RT_E_ARG;
+    const uint32_t n = sph->n;
+    for (uint32_t k = 0; k < n; ++k)
+        if (sph->kind[k] > RT_DIELECTRIC) return RT_E_ARG;
+    std::vector<float4> geom(n), aux(n), alb(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const float rad = sph->radius[k];
+        geom[k] = make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad);   // raytracer.zig:51 radius*radius
+        float kind_bits; std::memcpy(&kind_bits, &sph->kind[k], 4);
+        aux[k] = make_float4(rad, kind_bits, sph->param[k], 0.0f);
+        alb[k] = make_float4(sph->r[k], sph->g[k], sph->b[k], 0.0f);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+    ctx->d_geom = ctx->d_aux = ctx->d_albedo = nullptr; ctx->n_sph = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_geom, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aux, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_albedo, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_albedo, alb.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    ctx->n_sph = n;
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
+                     uint32_t *d_raycount, void *stream_, rt_stats *stats)
+{
+    if (!ctx || !cam || !d_accum_sum) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    rc = enqueue_trace(ctx, cam, cfg, d_accum_sum, d_raycount, stream);
+    if (rc != RT_OK) return rc;
+    if (stats) return read_stats(ctx, stream, stats);
+    return RT_OK;
+}
+
+int rt_tonemap_device(rt_ctx *ctx, const float *d_accum_sum, uint32_t n_pixels, uint32_t spp_total,
+                      float *d_mean, uint8_t *d_rgb8, void *stream_)
+{
+    if (!ctx || !d_accum_sum || spp_total == 0) return RT_E_ARG;
+    if ((uint64_t)n_pixels * 3 > 0xFFFFFFFFull) return RT_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    HIP_TRY(ctx, rt_launch_tonemap(d_accum_sum, n_pixels, spp_total, d_mean, d_rgb8, stream));
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *accum_mean, uint8_t *rgb8,
+              uint32_t *raycount, rt_stats *stats)
+{
+    if (!ctx || !cam) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    if (ctx->n_sph == 0) return RT_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)cfg->nx * cfg->ny;
+    if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_mean, ctx->mean_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_rgb8, ctx->rgb8_cap, npix * 3)) != RT_OK) return rc;
+    if (raycount && (rc = ensure(ctx, ctx->d_raycount, ctx->raycount_cap, npix)) != RT_OK) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, npix * 3 * sizeof(float), st));
+    if (raycount) HIP_TRY(ctx, hipMemsetAsync(ctx->d_raycount, 0, npix * sizeof(uint32_t), st));
+    rc = enqueue_trace(ctx, cam, cfg, ctx->d_accum, raycount ? ctx->d_raycount : nullptr, st);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, rt_launch_tonemap(ctx->d_accum, (uint32_t)npix, cfg->spp_total, ctx->d_mean, ctx->d_rgb8, st));
+    if (accum_mean) HIP_TRY(ctx, hipMemcpyAsync(accum_mean, ctx->d_mean, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (rgb8) HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->d_rgb8, npix * 3, hipMemcpyDeviceToHost, st));
+    if (raycount) HIP_TRY(ctx, hipMemcpyAsync(raycount, ctx->d_raycount, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (stats) { if ((rc = read_stats(ctx, st, stats)) != RT_OK) return rc; }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_render_and_write(rt_ctx *ctx, const char *fname, const rt_camera *cam, const rt_config *cfg, rt_stats *stats)
+{
+    if (!fname || !cfg) return RT_E_ARG;
+    std::vector<uint8_t> img((size_t)cfg->nx * cfg->ny * 3);
+    const int rc = rt_render(ctx, cam, cfg, nullptr, img.data(), nullptr, stats);
+    if (rc != RT_OK) return rc;
+    return rt_write_ppm(fname, img.data(), cfg->nx, cfg->ny);
+}
+
+// ---- host-side mirrors ------------------------------------------------------------------------
+
+void rt_camera_basic(rt_camera *cam)
+{
+    if (cam) *cam = rt::BasicCamera{}.to_abi();
+}
+
+void rt_camera_set_position(rt_camera *cam, const float lookfrom[3], const float lookat[3], const float v_up[3],
+                            float vfov_deg, float aspect)
+{
+    if (!cam) return;
+    rt::MovableCamera c;
+    c.SetPosition({ lookfrom[0], lookfrom[1], lookfrom[2] }, { lookat[0], lookat[1], lookat[2] },
+                  { v_up[0], v_up[1], v_up[2] }, vfov_deg, aspect);
+    *cam = c.to_abi();
+}
+
+int rt_random_scene(uint32_t half_size, uint64_t seed, uint32_t cap, float *cx, float *cy, float *cz, float *radius,
+                    uint32_t *kind, float *r, float *g, float *b, float *param)
+{
+    rt::RndGen rng = rt::RndGen::init(seed);
+    const rt::Hittable world = rt::Random_Scene(half_size, rng);
+    if (world.objects.size() > cap) return RT_E_CAP;
+    if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
+    soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
+    return (int)world.objects.size();
+}
+
+int rt_two_sphere_scene(uint32_t cap, float *cx, float *cy, float *cz, float *radius, uint32_t *kind, float *r,
+                        float *g, float *b, float *param)
+{
+    const rt::Hittable world = rt::Two_Sphere_Scene();
+    if (world.objects.size() > cap) return RT_E_CAP;
+    if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
+    soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
+    return (int)world.objects.size();
+}
+
+int rt_tessellate_spheres(const rt_spheres *sph, int slices, int stacks, uint32_t cap, float *v0, float *v1,
+                          float *v2, uint32_t *material)
+{
+    if (!sph || !sph->cx || !sph->cy || !sph->cz || !sph->radius) return RT_E_ARG;
+    std::vector<rt::Sphere> objs(sph->n);
+    for (uint32_t k = 0; k < sph->n; ++k) {
+        objs[k].center = { sph->cx[k], sph->cy[k], sph->cz[k] };
+        objs[k].radius = sph->radius[k];
+    }
+    const std::vector<rt::Triangle> tris = rt::Tessellate_Spheres(objs, slices, stacks);
+    if (cap == 0) return (int)tris.size();
+    if (tris.size() > cap) return RT_E_CAP;
+    if (!v0 || !v1 || !v2 || !material) return RT_E_ARG;
+    for (size_t k = 0; k < tris.size(); ++k) {
+        v0[3 * k] = tris[k].v0.x; v0[3 * k + 1] = tris[k].v0.y; v0[3 * k + 2] = tris[k].v0.z;
+        v1[3 * k] = tris[k].v1.x; v1[3 * k + 1] = tris[k].v1.y; v1[3 * k + 2] = tris[k].v1.z;
+        v2[3 * k] = tris[k].v2.x; v2[3 * k + 1] = tris[k].v2.y; v2[3 * k + 2] = tris[k].v2.z;
+        material[k] = tris[k].material;
+    }
+    return (int)tris.size();
+}
+
+int rt_write_ppm(const char *fname, const uint8_t *rgb8, uint32_t nx, uint32_t ny)
+{
+    if (!fname || !rgb8) return RT_E_ARG;
+    return rt::img_io::write_ppm_image(fname, rgb8, nx, ny) ? RT_OK : RT_E_IO;
+}
+
+int rt_selftest_math(rt_ctx *ctx, uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
+                     float *out_cbrt, const uint32_t *ctr0, uint32_t *philox_out)
+{
+    if (!ctx || !a || !b || !out_div || !out_sqrt || !out_cbrt || !ctr0 || !philox_out) return RT_E_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;
+    const size_t words = (size_t)n * 10;   // a, b, div, sqrt, cbrt, ctr0, philox[4]
+    HIP_TRY(ctx, hipMalloc((void **)&d, words * 4));
+    float *da = d, *db = d + n, *ddiv = d + 2 * (size_t)n, *dsq = d + 3 * (size_t)n, *dcb = d + 4 * (size_t)n;
+    uint32_t *dc = (uint32_t *)(d + 5 * (size_t)n), *dp = (uint32_t *)(d + 6 * (size_t)n);
+    int rc = RT_OK;
+    hipError_t e;
+    do {
+        if ((e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(dc, ctr0, n * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = rt_launch_selftest(n, da, db, ddiv, dsq, dcb, dc, dp, ctx->stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpy(out_div, ddiv, n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(out_sqrt, dsq, n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(out_cbrt, dcb, n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(philox_out, dp, (size_t)n * 16, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; rc = RT_E_HIP; }
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"
