@@ -64,6 +64,14 @@ def load():
         raise ImportError(
             "raytrace_amd: %s is missing -- build it with `make -C raytrace_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and a second copy loaded
+    # before it leaves torch without a device ("No HIP GPUs are available").  When torch is installed,
+    # load it first so librt_hip.so binds to the runtime that is already resident (same SONAME).
+    if os.environ.get("RT_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -1,0 +1,284 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP trace path, called through the C ABI,
+against the CPU oracle on the same seeded inputs and against the committed golden vectors.
+
+Bars (north_star / BASELINE.md):
+  * integer work bit-exact: pixel indexing, sample assignment, per-pixel ray counts (every branch
+    decision of every path), RNG streams;
+  * linear accumulation: max |gpu - oracle| <= 1e-3 per pixel channel (TOL_ACCUM below; measured
+    values are ~1e-7 because only the attenuation-product order differs);
+  * final u8 image: PSNR >= 60 dB.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytrace_amd as R
+from raytrace_amd import _lib
+from helpers import psnr_u8, spheres_to_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACCUM = 1e-3     # north_star: per-pixel max abs error on the linear accumulation buffer
+MIN_PSNR = 60.0      # north_star: PSNR on the final image
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+
+
+def _scene(name, nx, ny):
+    if name == "book":
+        s = R.Random_Scene(11, 0)
+        return s, R.book_camera(nx, ny), O.book_camera(nx, ny)
+    s = R.Two_Sphere_Scene()
+    return s, R.BasicCamera(), O.camera_basic()
+
+
+def _compare(res, oa, o8, orc, cnt):
+    assert res.rays == cnt["rays"] and res.primary_rays == cnt["primary_rays"]
+    assert np.array_equal(res.raycount, orc), "per-pixel ray counts differ: some branch decision diverged"
+    err = float(np.abs(res.accum - oa).max())
+    assert err <= TOL_ACCUM, err
+    assert psnr_u8(res.rgb8, o8) >= MIN_PSNR
+    assert np.all(np.isfinite(res.accum)) and np.all(res.accum >= 0)      # check_nan3 / check_neg3
+    return err
+
+
+def _both(ctx, name, nx, ny, spp, **kw):
+    s, cam, ocam = _scene(name, nx, ny)
+    ctx.upload_scene(s)
+    okw = dict(kw)
+    tile = okw.pop("tile", None)
+    res = ctx.render(cam, R.make_config(nx, ny, spp, tile=tile, **kw), want_raycount=True)
+    w = O.World(spheres=spheres_to_oracle(s))
+    ref = O.render_counter(w, ocam, O.make_config(nx, ny, spp, **okw))
+    return res, ref
+
+
+# ---- arithmetic primitives on the device, bit for bit -------------------------------------------------
+def test_device_math_is_bit_exact(gpu_ctx):
+    rng = np.random.default_rng(0)
+    n = 1 << 16
+    a = np.abs(rng.standard_normal(n).astype(np.float32)) * np.float32(10.0) ** rng.integers(-30, 30, n).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-12, 12, n).astype(np.float32)
+    a[:8] = [0.0, 1.0, 4.0, 1e-40, 3.4e38, 2.0, 1e-45, 0.5]      # zeros, denormals, extremes
+    ctr = (np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    d, s, c, ph = gpu_ctx.selftest_math(a, b, ctr)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(d.view(np.uint32), (a / b).view(np.uint32)), "f32 divide is not IEEE-exact"
+        assert np.array_equal(s.view(np.uint32), np.sqrt(a).view(np.uint32)), "f32 sqrt is not IEEE-exact"
+    L = O.lib()
+    oc = np.array([L.orc_cbrtf(float(x)) for x in a[:8192]], dtype=np.float32)
+    assert np.array_equal(c[:8192].view(np.uint32), oc.view(np.uint32)), "cbrt differs from the oracle"
+    key = (C.c_uint32 * 2)(0x12345678, 0x9abcdef0)
+    out = (C.c_uint32 * 4)()
+    for k in list(range(64)) + [n - 1]:
+        L.orc_philox4x32_10((C.c_uint32 * 4)(int(ctr[k]), k, 7, 0), key, out)
+        assert list(out) == ph[k].tolist()
+
+
+# ---- golden vectors ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["book", "two"])
+@pytest.mark.parametrize("depth", [16, 10])
+def test_golden_vectors(gpu_ctx, name, depth):
+    s, cam, _ = _scene(name, 32, 18)
+    gpu_ctx.upload_scene(s)
+    res = gpu_ctx.render(cam, R.make_config(32, 18, 4, max_depth=depth, seed=1), want_raycount=True)
+    key = "%s_d%d" % (name, depth)
+    assert np.array_equal(res.raycount, GOLD[key + "_raycount"].astype(np.uint32))
+    assert res.rays == int(GOLD[key + "_rays"])
+    assert float(np.abs(res.accum - GOLD[key + "_accum"]).max()) <= TOL_ACCUM
+    assert psnr_u8(res.rgb8, GOLD[key + "_rgb8"]) >= MIN_PSNR
+
+
+# ---- BASELINE configs --------------------------------------------------------------------------------
+def test_c1_book_400x225_10spp_depth10(gpu_ctx):
+    """configs[0]: the CPU-runnable case, whole image against the oracle."""
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", 400, 225, 10, max_depth=10)
+    err = _compare(res, oa, o8, orc, cnt)
+    print("C1 max|accum err| = %.3g, PSNR = %s" % (err, psnr_u8(res.rgb8, o8)))
+
+
+def test_c2_two_sphere_reduced(gpu_ctx):
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "two", 320, 180, 16)
+    _compare(res, oa, o8, orc, cnt)
+
+
+@pytest.mark.parametrize("name,spp", [("two", 100), ("book", 100)])
+def test_full_size_1080p_sampled_pixels(gpu_ctx, name, spp):
+    """configs[1] / configs[2] at full size: the counter RNG makes every pixel independent, so the
+    oracle renders a random subset of pixels at full spp and the GPU image must match there; plus
+    size-independent properties of the whole image."""
+    nx, ny = 1920, 1080
+    s, cam, ocam = _scene(name, nx, ny)
+    gpu_ctx.upload_scene(s)
+    res = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    rng = np.random.default_rng(11)
+    pix = np.unique(np.concatenate([rng.integers(0, nx * ny, 1500), [0, nx - 1, nx * ny - nx, nx * ny - 1]])).astype(np.uint32)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, o8, orc, _ = O.render_counter(w, ocam, O.make_config(nx, ny, spp), pixels=pix)
+    assert np.array_equal(res.raycount[pix], orc)
+    err = float(np.abs(res.accum[pix] - oa).max())
+    assert err <= TOL_ACCUM, err
+    assert psnr_u8(res.rgb8[pix], o8) >= MIN_PSNR
+    # whole-image properties
+    assert res.primary_rays == nx * ny * spp
+    assert res.rays == int(res.raycount.astype(np.uint64).sum())
+    assert np.all(res.raycount >= spp) and np.all(res.raycount <= spp * 18)    # 1..18 rays per path (Q5)
+    assert np.all(np.isfinite(res.accum)) and res.accum.min() >= 0 and res.accum.max() <= 1.0 + 1e-5
+    q = np.clip((255.99 * np.sqrt(res.accum)).astype(np.int32), 0, 255).astype(np.uint8)
+    assert np.array_equal(q, res.rgb8)                                          # tonemap (raytracer.zig:527)
+    print("%s 1080p/%dspp: %d rays, kernel %.1f ms = %.0f Mrays/s, sampled max err %.3g"
+          % (name, spp, res.rays, res.kernel_ms, res.rays / res.kernel_ms / 1e3, err))
+
+
+# ---- sharding properties -----------------------------------------------------------------
+def test_spp_ranges_sum_to_the_whole(gpu_ctx):
+    nx, ny, spp = 160, 90, 12
+    s, cam, _ = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    full = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    parts = [gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_begin=b, spp_end=e, spp_total=spp), want_raycount=True)
+             for b, e in ((0, 5), (5, 6), (6, 12))]
+    assert np.array_equal(sum(p.raycount for p in parts), full.raycount)        # sample assignment bit-exact
+    np.testing.assert_allclose(sum(p.accum for p in parts), full.accum, rtol=0, atol=1e-6)
+    empty = gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_begin=4, spp_end=4, spp_total=spp), want_raycount=True)
+    assert empty.rays == 0 and not empty.accum.any() and not empty.raycount.any()
+
+
+def test_tiles_equal_the_subrectangle(gpu_ctx):
+    nx, ny, spp = 100, 60, 4
+    s, cam, _ = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    full = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    acc = np.zeros_like(full.accum).reshape(ny, nx, 3)
+    cnt = np.zeros(ny * nx, np.uint32).reshape(ny, nx)
+    for tile in ((0, 0, 37, 60), (37, 0, 100, 23), (37, 23, 100, 60)):
+        t = gpu_ctx.render(cam, R.make_config(nx, ny, spp, tile=tile), want_raycount=True)
+        x0, y0, x1, y1 = tile
+        ta, tc = t.accum.reshape(ny, nx, 3), t.raycount.reshape(ny, nx)
+        mask = np.zeros((ny, nx), bool); mask[y0:y1, x0:x1] = True
+        assert not ta[~mask].any() and not tc[~mask].any()                      # nothing written outside the tile
+        acc += ta; cnt += tc
+    assert np.array_equal(cnt.ravel(), full.raycount)
+    assert np.array_equal(acc.reshape(-1, 3).view(np.uint32), full.accum.view(np.uint32))   # same lanes' arithmetic
+
+
+def test_runs_are_deterministic(gpu_ctx):
+    s, cam, _ = _scene("book", 200, 120)
+    gpu_ctx.upload_scene(s)
+    a = gpu_ctx.render(cam, R.make_config(200, 120, 6), want_raycount=True)
+    b = gpu_ctx.render(cam, R.make_config(200, 120, 6), want_raycount=True)
+    assert np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32)) and np.array_equal(a.raycount, b.raycount)
+    c = gpu_ctx.render(cam, R.make_config(200, 120, 6, seed=2), want_raycount=True)
+    assert not np.array_equal(a.raycount, c.raycount)                           # the seed matters
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nx,ny,spp,kw", [
+    (37, 19, 3, {}),                       # ragged: not a multiple of the 8x8 work tile
+    (1, 1, 5, {}),                         # single pixel
+    (7, 3, 1, {}),                         # smaller than one tile, one sample
+    (64, 36, 2, {"max_depth": 0}),         # depth cap 0: primary hit scatters once, second hit is black
+    (64, 36, 2, {"max_depth": 3}),
+    (48, 27, 3, {"row_offset_q3": 0}),     # the un-quirked row mapping
+    (48, 27, 3, {"seed": 0xDEADBEEFCAFEF00D}),   # 64-bit key
+    (48, 27, 2, {"t_min": 0.0}),
+])
+def test_edge_cases(gpu_ctx, nx, ny, spp, kw):
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", nx, ny, spp, **kw)
+    _compare(res, oa, o8, orc, cnt)
+
+
+def test_spp_offset_uses_global_sample_indices(gpu_ctx):
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", 40, 24, 9, spp_begin=5, spp_end=9, spp_total=9)
+    _compare(res, oa, o8, orc, cnt)
+
+
+def test_negative_radius_and_big_index_spheres(gpu_ctx):
+    """Hollow glass (negative radius, raytracer.zig:677) and index up to 10 (Schlick cosine > 1, Q8)."""
+    s = R.Spheres(cx=[0, 0, 0, 1.2], cy=[0, 0, -100.5, 0], cz=[-1, -1, -1, -1.5], radius=[0.5, -0.45, 100, 0.4],
+                  kind=[2, 2, 0, 2], r=[0.95, 0.95, 0.5, 0.95], g=[0.95, 0.95, 0.5, 0.95], b=[0.95, 0.95, 0.5, 0.95],
+                  param=[1.5, 1.5, 0, 9.7])
+    gpu_ctx.upload_scene(s)
+    res = gpu_ctx.render(R.BasicCamera(), R.make_config(96, 54, 8), want_raycount=True)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(96, 54, 8))
+    _compare(res, oa, o8, orc, cnt)
+    assert cnt["scatter_dielectric"] > 1000
+
+
+def test_depth_histogram_matches_oracle(gpu_ctx):
+    s, cam, ocam = _scene("book", 96, 54)
+    gpu_ctx.upload_scene(s)
+    gpu_ctx.set_flags(R.RT_FLAG_DEPTH_HISTOGRAM)
+    try:
+        res = gpu_ctx.render(cam, R.make_config(96, 54, 6), want_raycount=True)
+    finally:
+        gpu_ctx.set_flags(0)
+    w = O.World(spheres=spheres_to_oracle(s))
+    _, _, orc, cnt = O.render_counter(w, ocam, O.make_config(96, 54, 6))
+    assert np.array_equal(res.raycount, orc)
+    assert res.rays_by_depth[:19] == cnt["rays_by_depth"][:19] and sum(res.rays_by_depth) == res.rays
+
+
+def test_error_codes(gpu_ctx):
+    fresh = R.Context(0)
+    try:
+        with pytest.raises(R.RtError) as e:                                    # render before upload
+            fresh.render(R.BasicCamera(), R.make_config(8, 8, 1))
+        assert e.value.code == _lib.RT_E_STATE
+    finally:
+        fresh.close()
+    gpu_ctx.upload_scene(R.Two_Sphere_Scene())
+    for bad in (R.make_config(0, 8, 1), R.make_config(8, 8, 1, spp_begin=3, spp_end=2),
+                R.make_config(8, 8, 1, tile=(4, 0, 2, 8)), R.make_config(8, 8, 1, tile=(0, 0, 9, 8)),
+                R.make_config(8, 8, 1, spp_total=0, spp_end=1)):
+        with pytest.raises(R.RtError) as e:
+            gpu_ctx.render(R.BasicCamera(), bad)
+        assert e.value.code == _lib.RT_E_ARG
+    s = R.Two_Sphere_Scene(); s.kind[0] = 7
+    with pytest.raises(R.RtError):
+        gpu_ctx.upload_scene(s)
+
+
+# ---- device-resident entry points (what bench.py and the multi-GPU driver use) ----------------------------
+def test_render_device_and_tonemap_device(gpu_ctx):
+    import torch
+    nx, ny, spp = 128, 72, 8
+    s, cam, _ = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    host = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    acc = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+    rc = torch.zeros(nx * ny, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rays = 0
+    for b, e in ((0, 3), (3, 8)):                                               # two passes ADD into the buffer
+        r, _, _, _ = gpu_ctx.render_device(cam, R.make_config(nx, ny, spp, spp_begin=b, spp_end=e, spp_total=spp),
+                                           acc.data_ptr(), rc.data_ptr(), st)
+        rays += r
+    mean = torch.empty_like(acc)
+    rgb = torch.empty(nx * ny * 3, dtype=torch.uint8, device="cuda")
+    gpu_ctx.tonemap_device(acc.data_ptr(), nx * ny, spp, mean.data_ptr(), rgb.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert rays == host.rays
+    assert np.array_equal(rc.cpu().numpy().astype(np.uint32), host.raycount)
+    np.testing.assert_allclose(mean.cpu().numpy().reshape(-1, 3), host.accum, rtol=0, atol=1e-6)
+    assert psnr_u8(rgb.cpu().numpy().reshape(-1, 3), host.rgb8) >= MIN_PSNR
+
+
+def test_render_and_write_ppm(gpu_ctx, tmp_path):
+    """render_and_write (raytracer.zig:580-633) -> the same P3 file the oracle writes for its image."""
+    nx, ny, spp = 48, 27, 4
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    f = str(tmp_path / "Scene.ppm")
+    gpu_ctx.render_and_write(f, cam, R.make_config(nx, ny, spp))
+    w = O.World(spheres=spheres_to_oracle(s))
+    _, o8, _, _ = O.render_counter(w, ocam, O.make_config(nx, ny, spp))
+    g = str(tmp_path / "Oracle.ppm")
+    assert O.lib().orc_write_ppm(g.encode(), o8.ctypes.data, nx, ny) == 0
+    a = np.loadtxt(f, skiprows=3, dtype=np.int64)
+    b = np.loadtxt(g, skiprows=3, dtype=np.int64)
+    assert open(f).read().split("\n")[:3] == ["P3", "%d %d" % (nx, ny), "255"]
+    assert psnr_u8(a, b) >= MIN_PSNR

@@ -1,0 +1,106 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/rt_hip.h declares, and the host mirrors of the reference API (camera, scene generator,
+tessellator, PPM writer) agree bit-for-bit with the oracle.  No compute call is made without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytrace_amd as R
+from raytrace_amd import _lib
+from helpers import spheres_to_oracle, triangles_to_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.rt_camera) == 52
+    assert C.sizeof(_lib.rt_config) == 64 and _lib.rt_config.seed.offset == 32
+    assert C.sizeof(_lib.rt_stats) == 8 + 8 + 8 + 160
+    assert C.sizeof(_lib.rt_spheres) == 8 + 9 * 8
+
+
+def test_strerror():
+    L = _lib.load()
+    assert L.rt_strerror(0) == b"ok"
+    assert b"argument" in L.rt_strerror(_lib.RT_E_ARG)
+    assert b"HIP" in L.rt_strerror(_lib.RT_E_HIP)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_no_gpu_fails_loudly():
+    """There is no CPU fallback: creating a context without a device is an error, not a silent detour."""
+    with pytest.raises(R.RtError) as e:
+        R.Context(0)
+    assert e.value.code == _lib.RT_E_HIP
+
+
+def test_cameras_match_oracle_bitwise():
+    assert np.array_equal(R.BasicCamera().as_array(), O.camera_basic().as_array())
+    for nx, ny in ((1200, 675), (1920, 1080), (400, 225), (64, 36)):
+        a = R.book_camera(nx, ny)
+        b = O.book_camera(nx, ny)
+        assert np.array_equal(a.as_array().view(np.uint32), b.as_array().view(np.uint32))
+        assert a.to_abi().subtract_origin == 1
+    # the GUI's odd call (main.zig:308-315): forward vector as look-at, pos + (0,1,0) as up
+    pos, fwd = (3.0, 1.5, -2.0), (0.3, -0.1, 0.9)
+    a = R.MovableCamera().SetPosition(pos, fwd, (3.0, 2.5, -2.0), 45.0, 1200 / 675)
+    b = O.camera_set_position(pos, fwd, (3.0, 2.5, -2.0), 45.0, 1200 / 675)
+    assert np.array_equal(a.as_array().view(np.uint32), b.as_array().view(np.uint32))
+
+
+@pytest.mark.parametrize("half,seed", [(11, 0), (3, 0), (5, 123), (11, 246)])
+def test_random_scene_matches_oracle_bitwise(half, seed):
+    a = spheres_to_oracle(R.Random_Scene(half, seed))
+    b = O.random_scene(half, seed)
+    assert len(a) == len(b)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_two_sphere_scene_matches_oracle():
+    assert spheres_to_oracle(R.Two_Sphere_Scene()).tobytes() == O.two_sphere_scene().tobytes()
+
+
+def test_random_scene_capacity_error():
+    L = _lib.load()
+    s = R.Spheres.empty(4)
+    assert L.rt_random_scene(11, 0, 4, *s._out_ptrs()) == _lib.RT_E_CAP
+
+
+@pytest.mark.parametrize("sl,st", [(12, 8), (0, 0)])
+def test_tessellation_matches_oracle_bitwise(sl, st):
+    src = R.Random_Scene(2, 0)
+    a = triangles_to_oracle(R.Tessellate_Spheres(src, sl, st))
+    b = O.tessellate(spheres_to_oracle(src), sl, st)
+    assert len(a) == len(b) and a.tobytes() == b.tobytes()
+
+
+def test_ppm_writer_matches_reference_format(tmp_path):
+    """write_ppm_image, image.zig:28-34."""
+    img = (np.arange(4 * 2 * 3) * 9 % 256).astype(np.uint8).reshape(8, 3)
+    f = str(tmp_path / "a.ppm")
+    g = str(tmp_path / "b.ppm")
+    R.write_ppm_image(f, img, 4, 2)
+    assert O.lib().orc_write_ppm(g.encode(), img.ctypes.data, 4, 2) == 0
+    txt = open(f).read()
+    assert txt == open(g).read()
+    assert txt.startswith("P3\n4 2\n255\n") and txt.count("\n") == 3 + 8
+
+
+def test_config_defaults_are_the_reference_constants():
+    cfg = R.make_config(1200, 675, 25)
+    assert cfg.max_depth == 16 and abs(cfg.t_min - 0.001) < 1e-9 and cfg.row_offset_q3 == 1
+    assert (cfg.spp_begin, cfg.spp_end, cfg.spp_total) == (0, 25, 25)
