@@ -82,7 +82,11 @@ typedef struct {
     uint64_t rays_by_depth[20];      /* filled only when RT_FLAG_DEPTH_HISTOGRAM is set */
 } rt_stats;
 
-enum { RT_FLAG_DEPTH_HISTOGRAM = 1u };
+enum {
+    RT_FLAG_DEPTH_HISTOGRAM = 1u,    /* fill rt_stats.rays_by_depth */
+    RT_FLAG_FORCE_BRUTE_FORCE = 2u,  /* spheres: always the brute-force (list) kernel */
+    RT_FLAG_FORCE_BVH = 4u           /* spheres: always the BVH kernel */
+};
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Replaces nothing in the reference (its path is pure CPU); mirrors compute.zig:19-29 Compute.create. */
@@ -93,9 +97,17 @@ int  rt_last_hip_error(const rt_ctx *ctx);   /* hipError_t of the last failing H
 int  rt_set_flags(rt_ctx *ctx, uint32_t flags);
 
 /* ---- scene upload: the `world: Hittable` argument of Render (raytracer.zig:517) ------------- */
-/* spheres and/or triangles; `materials` is required when triangles are given. */
+/* Exactly one of spheres / triangles per scene; `materials` (kind, r, g, b, param) is required with
+ * triangles.  Replaces the reference's CPU acceleration build (build_BVH, raytracer.zig:279-376): the
+ * library builds its own GPU BVH here. */
 int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *triangles,
                     const rt_spheres *materials);
+
+/* What the last upload built (any pointer may be NULL). */
+int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
+                  uint32_t *bvh_depth);
+/* Name of the trace kernel the last render launched (for profiles). */
+const char *rt_last_kernel_name(const rt_ctx *ctx);
 
 /* ---- the trace path --------------------------------------------------------------------------
  * rt_render replaces the fan-out + join + average of render_and_write (raytracer.zig:588-617), i.e.

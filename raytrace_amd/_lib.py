@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
 RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2
-RT_FLAG_DEPTH_HISTOGRAM = 1
+RT_FLAG_DEPTH_HISTOGRAM, RT_FLAG_FORCE_BRUTE_FORCE, RT_FLAG_FORCE_BVH = 1, 2, 4
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -47,6 +47,7 @@ class rt_stats(C.Structure):
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
+    "rt_scene_info", "rt_last_kernel_name",
     "rt_render", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
     "rt_selftest_math",
@@ -86,6 +87,10 @@ def load():
     L.rt_set_flags.restype = C.c_int
     L.rt_upload_scene.argtypes = [vp, C.POINTER(rt_spheres), C.POINTER(rt_triangles), C.POINTER(rt_spheres)]
     L.rt_upload_scene.restype = C.c_int
+    L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]
+    L.rt_scene_info.restype = C.c_int
+    L.rt_last_kernel_name.argtypes = [vp]
+    L.rt_last_kernel_name.restype = C.c_char_p
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
     L.rt_render.restype = C.c_int
     L.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]

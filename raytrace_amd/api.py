@@ -236,6 +236,14 @@ class Context:
                                      C.byref(mv) if mv is not None else None)
         self._check(rc, "rt_upload_scene")
 
+    def scene_info(self):
+        vals = [C.c_uint32() for _ in range(4)]
+        self._check(self._L.rt_scene_info(self._h, *[C.byref(x) for x in vals]), "rt_scene_info")
+        return dict(zip(("n_spheres", "n_triangles", "n_bvh_nodes", "bvh_depth"), [int(x.value) for x in vals]))
+
+    def last_kernel_name(self):
+        return self._L.rt_last_kernel_name(self._h).decode()
+
     def render(self, cam, cfg, want_raycount=False):
         """rt_render: host images out.  Blocking."""
         n = cfg.nx * cfg.ny

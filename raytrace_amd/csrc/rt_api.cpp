@@ -13,6 +13,7 @@
 
 #include "../../include/rt_hip.h"
 #include "../host/raytracer.hpp"
+#include "rt_bvh.hpp"
 #include "rt_kernels.h"
 
 struct rt_ctx {
@@ -22,9 +23,11 @@ struct rt_ctx {
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
     int          last_hip = 0;
-    // scene
-    float4      *d_geom = nullptr, *d_aux = nullptr, *d_albedo = nullptr;
-    uint32_t     n_sph = 0;
+    // scene (one kind of primitive at a time: spheres or triangles)
+    float4      *d_geom = nullptr, *d_tri = nullptr, *d_aux = nullptr, *d_albedo = nullptr, *d_bvh = nullptr;
+    uint32_t     n_sph = 0, n_tri = 0, n_nodes = 0;
+    int          bvh_depth = 0;
+    TraceKernel  last_kernel = RT_K_BRUTE_SPHERES;
     // per-render scratch owned by the ctx
     uint32_t    *d_queue = nullptr;            // work-queue head
     unsigned long long *d_stats = nullptr;     // RT_STATS_WORDS
@@ -93,26 +96,36 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.n_prim = n_prim;
 }
 
+// Spheres up to this count are traced by the brute-force kernel (one scalar-fed loop, no divergence);
+// above it the BVH kernel wins (measured on MI355X).
+constexpr uint32_t BRUTE_FORCE_MAX_SPHERES = 16;
+
+TraceKernel pick_kernel(const rt_ctx *ctx)
+{
+    if (ctx->n_tri) return RT_K_BVH_TRIANGLES;
+    if (ctx->flags & RT_FLAG_FORCE_BRUTE_FORCE) return RT_K_BRUTE_SPHERES;
+    if (ctx->flags & RT_FLAG_FORCE_BVH) return RT_K_BVH_SPHERES;
+    return ctx->n_sph <= BRUTE_FORCE_MAX_SPHERES ? RT_K_BRUTE_SPHERES : RT_K_BVH_SPHERES;
+}
+
 // enqueue one trace pass on `stream`; timing events are recorded around the kernel
 int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
                   uint32_t *d_raycount, hipStream_t stream)
 {
-    if (ctx->n_sph == 0) return RT_E_STATE;
+    if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
     TraceParams p;
-    fill_params(p, cam, cfg, ctx->n_sph);
+    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
-    const int per_cu = rt_trace_spheres_blocks_per_cu(hist);
-    long long want = ((long long)p.n_items + 255) / 256;             // no more blocks than work
-    long long grid = (long long)ctx->num_cus * per_cu;
-    if (grid > want) grid = want;
-    if (grid < 1) grid = 1;
-    DeviceSpheres s{ ctx->d_geom, ctx->d_aux, ctx->d_albedo, ctx->n_sph };
+    DeviceScene s;
+    s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;
+    s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth;
+    ctx->last_kernel = pick_kernel(ctx);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (cfg->spp_end > cfg->spp_begin)
-        HIP_TRY(ctx, rt_launch_trace_spheres(p, s, d_accum_sum, d_raycount, ctx->d_queue, ctx->d_stats, hist,
-                                             (int)grid, stream));
+        HIP_TRY(ctx, rt_launch_trace(ctx->last_kernel, p, s, d_accum_sum, d_raycount, ctx->d_queue, ctx->d_stats, hist,
+                                     ctx->num_cus, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     return RT_OK;
 }
@@ -194,7 +207,8 @@ void rt_destroy(rt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+    (void)hipFree(ctx->d_bvh);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -212,36 +226,94 @@ int rt_set_flags(rt_ctx *ctx, uint32_t flags)
     return RT_OK;
 }
 
+static int upload_vec(rt_ctx *ctx, float4 *&dst, const std::vector<float4> &src)
+{
+    if (src.empty()) return RT_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&dst, sizeof(float4) * src.size()));
+    HIP_TRY(ctx, hipMemcpy(dst, src.data(), sizeof(float4) * src.size(), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+static bool spheres_valid(const rt_spheres *s, bool need_geometry)
+{
+    if (!s || s->n == 0 || !s->kind || !s->r || !s->g || !s->b || !s->param) return false;
+    if (need_geometry && (!s->cx || !s->cy || !s->cz || !s->radius)) return false;
+    for (uint32_t k = 0; k < s->n; ++k)
+        if (s->kind[k] > RT_DIELECTRIC) return false;
+    return true;
+}
+
 int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri, const rt_spheres *materials)
 {
     if (!ctx) return RT_E_ARG;
-    if (tri && tri->n) { (void)materials; return RT_E_ARG; }   // triangle path: not built yet
-    if (!sph || sph->n == 0) return RT_E_ARG;
-    if (!sph->cx || !sph->cy || !sph->cz || !sph->radius || !sph->kind || !sph->r || !sph->g || !sph->b || !sph->param)
-        return RT_E_ARG;
-    const uint32_t n = sph->n;
-    for (uint32_t k = 0; k < n; ++k)
-        if (sph->kind[k] > RT_DIELECTRIC) return RT_E_ARG;
-    std::vector<float4> geom(n), aux(n), alb(n);
-    for (uint32_t k = 0; k < n; ++k) {
-        const float rad = sph->radius[k];
-        geom[k] = make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad);   // raytracer.zig:51 radius*radius
-        float kind_bits; std::memcpy(&kind_bits, &sph->kind[k], 4);
-        aux[k] = make_float4(rad, kind_bits, sph->param[k], 0.0f);
-        alb[k] = make_float4(sph->r[k], sph->g[k], sph->b[k], 0.0f);
+    const bool have_sph = sph && sph->n, have_tri = tri && tri->n;
+    if (have_sph == have_tri) return RT_E_ARG;            // exactly one kind of primitive per scene
+    std::vector<float4> geom, tris, aux, alb;
+    std::vector<rtbvh::Prim> prims;
+    const rt_spheres *mats = have_sph ? sph : materials;
+    if (!spheres_valid(mats, have_sph)) return RT_E_ARG;
+    if (mats->n >= 0x7FFFFFFFu) return RT_E_ARG;
+    for (uint32_t k = 0; k < mats->n; ++k) {
+        float kind_bits; std::memcpy(&kind_bits, &mats->kind[k], 4);
+        aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k], 0.0f));
+        alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], 0.0f));
     }
+    if (have_sph) {
+        for (uint32_t k = 0; k < sph->n; ++k) {
+            const float rad = sph->radius[k];
+            geom.push_back(make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad));   // raytracer.zig:51
+            prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
+        }
+    } else {
+        if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= 0x7FFFFFFFu / 3) return RT_E_ARG;
+        for (uint32_t k = 0; k < tri->n; ++k) {
+            if (tri->material[k] >= mats->n) return RT_E_ARG;
+            const float *a = tri->v0 + 3 * (size_t)k, *b = tri->v1 + 3 * (size_t)k, *c = tri->v2 + 3 * (size_t)k;
+            float mat_bits; std::memcpy(&mat_bits, &tri->material[k], 4);
+            tris.push_back(make_float4(a[0], a[1], a[2], mat_bits));
+            tris.push_back(make_float4(b[0], b[1], b[2], 0.0f));
+            tris.push_back(make_float4(c[0], c[1], c[2], 0.0f));
+            prims.push_back(rtbvh::triangle_prim(a, b, c));
+        }
+    }
+    const rtbvh::Tree tree = rtbvh::build(prims);
+    if (tree.depth > rtbvh::MAX_DEPTH) return RT_E_ARG;
+    std::vector<float4> nodes(tree.nodes.size() * 4);
+    if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));
+
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
-    ctx->d_geom = ctx->d_aux = ctx->d_albedo = nullptr; ctx->n_sph = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_geom, sizeof(float4) * n));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aux, sizeof(float4) * n));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_albedo, sizeof(float4) * n));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_albedo, alb.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-    ctx->n_sph = n;
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+    (void)hipFree(ctx->d_bvh);
+    ctx->d_geom = ctx->d_tri = ctx->d_aux = ctx->d_albedo = ctx->d_bvh = nullptr;
+    ctx->n_sph = ctx->n_tri = ctx->n_nodes = 0; ctx->bvh_depth = 0;
+    int rc;
+    if ((rc = upload_vec(ctx, ctx->d_geom, geom)) != RT_OK) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_tri, tris)) != RT_OK) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_aux, aux)) != RT_OK) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_albedo, alb)) != RT_OK) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_bvh, nodes)) != RT_OK) return rc;
+    ctx->n_sph = have_sph ? sph->n : 0;
+    ctx->n_tri = have_tri ? tri->n : 0;
+    ctx->n_nodes = (uint32_t)tree.nodes.size();
+    ctx->bvh_depth = tree.depth;
     return RT_OK;
+}
+
+int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
+                  uint32_t *bvh_depth)
+{
+    if (!ctx) return RT_E_ARG;
+    if (n_spheres) *n_spheres = ctx->n_sph;
+    if (n_triangles) *n_triangles = ctx->n_tri;
+    if (n_bvh_nodes) *n_bvh_nodes = ctx->n_nodes;
+    if (bvh_depth) *bvh_depth = (uint32_t)ctx->bvh_depth;
+    return RT_OK;
+}
+
+const char *rt_last_kernel_name(const rt_ctx *ctx)
+{
+    return ctx ? rt_trace_kernel_name(ctx->last_kernel) : "";
 }
 
 int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
@@ -275,7 +347,7 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *ac
     if (!ctx || !cam) return RT_E_ARG;
     int rc = check_config(cfg);
     if (rc != RT_OK) return rc;
-    if (ctx->n_sph == 0) return RT_E_STATE;
+    if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)cfg->nx * cfg->ny;
     if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;

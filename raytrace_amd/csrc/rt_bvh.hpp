@@ -1,0 +1,179 @@
+// Host-side BVH builder for the GPU traversal kernels (binned SAH, one primitive per leaf).
+//
+// This is NOT the reference's build_BVH (raytracer.zig:279-376; depth 5, 2-axis slab test, quirks
+// Q1/Q2 in SURVEY 8(a)).  The contract with the reference is only the closest-hit answer of the
+// list traversal (raytracer.zig:92-113): the GPU BVH culls conservatively (boxes are padded) and the
+// primitive tests on the survivors are the exact ones, so the answer is the list's.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace rtbvh {
+
+struct Box {
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX };
+    float hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float p[3]) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.0f : dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim { Box box; float c[3]; };
+
+// 64-byte node: two child boxes + two child references.
+//   q0 = { lo0.x, lo0.y, lo0.z, hi0.x }   q1 = { hi0.y, hi0.z, lo1.x, lo1.y }
+//   q2 = { lo1.z, hi1.x, hi1.y, hi1.z }   q3 = { bits(child0), bits(child1), 0, 0 }
+// child reference: bit 31 set = leaf holding primitive (ref & 0x7fffffff); else inner node index;
+// 0xFFFFFFFF = empty (its box is inverted and can never be hit).
+struct Node { float w[16]; };
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr int MAX_DEPTH = 32;
+
+struct Tree {
+    std::vector<Node> nodes;
+    int depth = 0;          // number of inner-node levels (stack entries a traversal can need)
+};
+
+namespace detail {
+
+inline void set_child(Node &n, int which, const Box &b, uint32_t ref)
+{
+    float *w = n.w;
+    if (which == 0) { w[0] = b.lo[0]; w[1] = b.lo[1]; w[2] = b.lo[2]; w[3] = b.hi[0]; w[4] = b.hi[1]; w[5] = b.hi[2]; }
+    else { w[6] = b.lo[0]; w[7] = b.lo[1]; w[8] = b.lo[2]; w[9] = b.hi[0]; w[10] = b.hi[1]; w[11] = b.hi[2]; }
+    uint32_t *u = reinterpret_cast<uint32_t *>(w);
+    u[12 + which] = ref;
+}
+
+struct Builder {
+    const std::vector<Prim> &prims;
+    std::vector<uint32_t> idx;
+    Tree tree;
+    explicit Builder(const std::vector<Prim> &p) : prims(p), idx(p.size()) { for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i; }
+
+    // returns the reference of the subtree over idx[first, first+count) and its box
+    uint32_t build(uint32_t first, uint32_t count, int depth, Box &out_box)
+    {
+        out_box = Box();
+        for (uint32_t i = 0; i < count; ++i) out_box.grow(prims[idx[first + i]].box);
+        if (count == 1) return LEAF_BIT | idx[first];
+
+        Box cb;
+        for (uint32_t i = 0; i < count; ++i) cb.grow(prims[idx[first + i]].c);
+        // binned SAH over the three axes
+        constexpr int NB = 16;
+        float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            const float ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0)) continue;
+            Box bb[NB]; uint32_t bc[NB] = { 0 };
+            const float scale = NB / ext;
+            for (uint32_t i = 0; i < count; ++i) {
+                const Prim &p = prims[idx[first + i]];
+                int b = (int)((p.c[ax] - cb.lo[ax]) * scale);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                bb[b].grow(p.box); bc[b]++;
+            }
+            float right_area[NB]; uint32_t right_cnt[NB];
+            Box acc; uint32_t cnt = 0;
+            for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+            acc = Box(); cnt = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.grow(bb[b]); cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                const float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+            }
+        }
+        uint32_t mid = 0;
+        const uint64_t cap = depth + 1 >= MAX_DEPTH ? 1ull : (1ull << (MAX_DEPTH - depth - 1));   // per-child capacity
+        if (best_axis >= 0) {
+            const float ext = cb.hi[best_axis] - cb.lo[best_axis];
+            const float scale = NB / ext;
+            auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t pi) {
+                int b = (int)((prims[pi].c[best_axis] - cb.lo[best_axis]) * scale);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - (idx.begin() + first));
+        }
+        if (mid == 0 || mid == count || mid > cap || count - mid > cap) {
+            // degenerate or too deep: median split along the widest centroid axis
+            int ax = 0;
+            if (cb.hi[1] - cb.lo[1] > cb.hi[ax] - cb.lo[ax]) ax = 1;
+            if (cb.hi[2] - cb.lo[2] > cb.hi[ax] - cb.lo[ax]) ax = 2;
+            mid = count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + first + mid, idx.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return prims[a].c[ax] < prims[b].c[ax]; });
+        }
+        const uint32_t me = (uint32_t)tree.nodes.size();
+        tree.nodes.emplace_back();
+        tree.depth = std::max(tree.depth, depth + 1);
+        Box b0, b1;
+        const uint32_t r0 = build(first, mid, depth + 1, b0);
+        const uint32_t r1 = build(first + mid, count - mid, depth + 1, b1);
+        set_child(tree.nodes[me], 0, b0, r0);
+        set_child(tree.nodes[me], 1, b1, r1);
+        return me;
+    }
+};
+
+}  // namespace detail
+
+// Build over `prims` (boxes must already be padded).  nodes[0] is the root.
+inline Tree build(const std::vector<Prim> &prims)
+{
+    detail::Builder b(prims);
+    if (prims.empty()) return b.tree;
+    if (prims.size() == 1) {
+        b.tree.nodes.emplace_back();
+        detail::set_child(b.tree.nodes[0], 0, prims[0].box, LEAF_BIT | 0u);
+        detail::set_child(b.tree.nodes[0], 1, Box(), EMPTY);
+        b.tree.depth = 1;
+        return b.tree;
+    }
+    Box root;
+    b.tree.nodes.reserve(prims.size());
+    b.build(0, (uint32_t)prims.size(), 0, root);
+    return b.tree;
+}
+
+// Conservative padding: the box test may never cull a primitive its exact test would accept.  The
+// slab arithmetic carries a few ulps of the coordinates involved; pad by 1e-3 of the size plus 1e-5 of
+// the coordinate magnitude.
+inline Prim sphere_prim(float cx, float cy, float cz, float radius)
+{
+    Prim p;
+    const float c[3] = { cx, cy, cz };
+    const float r = std::fabs(radius);
+    for (int k = 0; k < 3; ++k) {
+        const float pad = 1e-3f * r + 1e-5f * (std::fabs(c[k]) + r) + 1e-30f;
+        p.box.lo[k] = c[k] - r - pad; p.box.hi[k] = c[k] + r + pad; p.c[k] = c[k];
+    }
+    return p;
+}
+inline Prim triangle_prim(const float v0[3], const float v1[3], const float v2[3])
+{
+    Prim p;
+    float ext = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = std::min(v0[k], std::min(v1[k], v2[k])), hi = std::max(v0[k], std::max(v1[k], v2[k]));
+        ext = std::max(ext, hi - lo);
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float lo = std::min(v0[k], std::min(v1[k], v2[k])), hi = std::max(v0[k], std::max(v1[k], v2[k]));
+        const float pad = 1e-3f * ext + 1e-5f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f;
+        p.box.lo[k] = lo - pad; p.box.hi[k] = hi + pad;
+        p.c[k] = (v0[k] + v1[k] + v2[k]) * (1.0f / 3.0f);
+    }
+    return p;
+}
+
+}  // namespace rtbvh

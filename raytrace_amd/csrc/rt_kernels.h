@@ -18,24 +18,33 @@ struct TraceParams {
     uint32_t n_prim;
 };
 
-// Device scene (sphere SoA, 16-byte records so one scalar/vector load fetches a whole record):
-//   geom[i]   = { cx, cy, cz, radius*radius }       -- all the inner loop reads
-//   aux[i]    = { radius, bits(kind), param, 0 }    -- read once per hit
-//   albedo[i] = { r, g, b, 0 }
-struct DeviceSpheres {
-    const float4 *geom;
-    const float4 *aux;
-    const float4 *albedo;
-    uint32_t      n;
+// Device scene.  16-byte records so one scalar/vector load fetches a whole record.
+//   spheres:   geom[i]   = { cx, cy, cz, radius*radius }   (all the brute-force inner loop reads)
+//              aux[i]    = { radius, bits(kind), param, 0 } (material i = sphere i)
+//              albedo[i] = { r, g, b, 0 }
+//   triangles: tri[3i+0] = { v0.xyz, bits(material) }, tri[3i+1] = { v1.xyz, 0 }, tri[3i+2] = { v2.xyz, 0 }
+//              aux/albedo are the material table (aux.x unused)
+//   bvh:       4 float4 per node (rt_bvh.hpp Node), root = node 0
+struct DeviceScene {
+    const float4 *geom = nullptr;
+    const float4 *tri = nullptr;
+    const float4 *aux = nullptr;
+    const float4 *albedo = nullptr;
+    const float4 *bvh = nullptr;
+    uint32_t      n_prim = 0;
+    uint32_t      n_nodes = 0;
+    int           bvh_depth = 0;
 };
+
+enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANGLES = 2 };
 
 // stats buffer layout (unsigned long long[]): [0] rays, [1] primary rays, [2..21] rays by depth
 enum { RT_STATS_WORDS = 22 };
 
-hipError_t rt_launch_trace_spheres(const TraceParams &p, const DeviceSpheres &s, float *accum_sum,
-                                   uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
-                                   bool histogram, int grid_blocks, hipStream_t stream);
-int rt_trace_spheres_blocks_per_cu(bool histogram);
+hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const DeviceScene &s, float *accum_sum,
+                           uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
+                           bool histogram, int num_cus, hipStream_t stream);
+const char *rt_trace_kernel_name(TraceKernel which);
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,
                              float *mean, uint8_t *rgb8, hipStream_t stream);
