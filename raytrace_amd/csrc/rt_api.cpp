@@ -277,7 +277,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         }
     }
     const rtbvh::Tree tree = rtbvh::build(prims);
-    if (tree.depth > rtbvh::MAX_DEPTH) return RT_E_ARG;
+    if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
     std::vector<float4> nodes(tree.nodes.size() * 4);
     if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));
 

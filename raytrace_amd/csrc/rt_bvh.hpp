@@ -29,11 +29,11 @@ struct Prim { Box box; float c[3]; };
 // 64-byte node: two child boxes + two child references.
 //   q0 = { lo0.x, lo0.y, lo0.z, hi0.x }   q1 = { hi0.y, hi0.z, lo1.x, lo1.y }
 //   q2 = { lo1.z, hi1.x, hi1.y, hi1.z }   q3 = { bits(child0), bits(child1), 0, 0 }
-// child reference: bit 31 set = leaf holding primitive (ref & 0x7fffffff); else inner node index;
-// 0xFFFFFFFF = empty (its box is inverted and can never be hit).
+// child reference: bit 31 set = leaf holding primitive (ref & 0x7fffffff); else inner node index.
+// Every node has two valid children (a one-primitive scene lists its leaf twice; there is no "empty"
+// reference, because an inverted box is NOT unhittable for a min/max slab test).
 struct Node { float w[16]; };
 constexpr uint32_t LEAF_BIT = 0x80000000u;
-constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 32;
 
 struct Tree {
@@ -135,7 +135,7 @@ inline Tree build(const std::vector<Prim> &prims)
     if (prims.size() == 1) {
         b.tree.nodes.emplace_back();
         detail::set_child(b.tree.nodes[0], 0, prims[0].box, LEAF_BIT | 0u);
-        detail::set_child(b.tree.nodes[0], 1, Box(), EMPTY);
+        detail::set_child(b.tree.nodes[0], 1, prims[0].box, LEAF_BIT | 0u);
         b.tree.depth = 1;
         return b.tree;
     }
@@ -143,6 +143,52 @@ inline Tree build(const std::vector<Prim> &prims)
     b.tree.nodes.reserve(prims.size());
     b.build(0, (uint32_t)prims.size(), 0, root);
     return b.tree;
+}
+
+// Structural check run at every upload (O(n)): every reference in range, every primitive in exactly
+// one leaf (twice for the one-primitive tree), every child box containing its subtree's primitives,
+// depth within the traversal stack.  A tree that fails is never sent to the GPU.
+inline bool validate(const Tree &t, const std::vector<Prim> &prims)
+{
+    const size_t n = prims.size();
+    if (n == 0) return t.nodes.empty();
+    if (t.nodes.size() != (n == 1 ? 1 : n - 1) || t.depth < 1 || t.depth > MAX_DEPTH) return false;
+    std::vector<uint32_t> seen(n, 0), node_seen(t.nodes.size(), 0);
+    struct Item { uint32_t node; int depth; };
+    std::vector<Item> stack{ { 0u, 1 } };
+    node_seen[0] = 1;
+    // subtree boxes are checked against the primitives' own boxes at the leaves and, for inner children,
+    // against the union of the grandchildren boxes (which is how the builder made them)
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.depth > t.depth) return false;
+        const Node &nd = t.nodes[it.node];
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(nd.w);
+        for (int c = 0; c < 2; ++c) {
+            const float *b = nd.w + 6 * c;
+            const uint32_t ref = u[12 + c];
+            for (int k = 0; k < 3; ++k) if (!(b[k] <= b[3 + k])) return false;
+            if (ref & LEAF_BIT) {
+                const uint32_t pi = ref & ~LEAF_BIT;
+                if (pi >= n) return false;
+                seen[pi]++;
+                for (int k = 0; k < 3; ++k)
+                    if (b[k] > prims[pi].box.lo[k] || b[3 + k] < prims[pi].box.hi[k]) return false;
+            } else {
+                if (ref >= t.nodes.size() || node_seen[ref]) return false;
+                node_seen[ref] = 1;
+                const Node &ch = t.nodes[ref];
+                for (int k = 0; k < 3; ++k) {
+                    const float lo = std::min(ch.w[k], ch.w[6 + k]), hi = std::max(ch.w[3 + k], ch.w[9 + k]);
+                    if (b[k] > lo || b[3 + k] < hi) return false;
+                }
+                stack.push_back({ ref, it.depth + 1 });
+            }
+        }
+    }
+    for (size_t i = 0; i < n; ++i) if (seen[i] != (n == 1 ? 2u : 1u)) return false;
+    for (uint32_t v : node_seen) if (!v) return false;
+    return true;
 }
 
 // Conservative padding: the box test may never cull a primitive its exact test would accept.  The

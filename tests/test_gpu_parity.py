@@ -17,7 +17,7 @@ import pytest
 import oracle_lib as O
 import raytrace_amd as R
 from raytrace_amd import _lib
-from helpers import psnr_u8, spheres_to_oracle
+from helpers import psnr_u8, spheres_to_oracle, triangles_to_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -44,12 +44,21 @@ def _compare(res, oa, o8, orc, cnt):
     return err
 
 
-def _both(ctx, name, nx, ny, spp, **kw):
+FLAVOURS = {"brute": R.RT_FLAG_FORCE_BRUTE_FORCE, "bvh": R.RT_FLAG_FORCE_BVH, "auto": 0}
+
+
+def _both(ctx, name, nx, ny, spp, flavour="auto", **kw):
     s, cam, ocam = _scene(name, nx, ny)
+    ctx.set_flags(FLAVOURS[flavour])
     ctx.upload_scene(s)
     okw = dict(kw)
     tile = okw.pop("tile", None)
-    res = ctx.render(cam, R.make_config(nx, ny, spp, tile=tile, **kw), want_raycount=True)
+    try:
+        res = ctx.render(cam, R.make_config(nx, ny, spp, tile=tile, **kw), want_raycount=True)
+    finally:
+        ctx.set_flags(0)
+    if flavour != "auto":
+        assert flavour in ctx.last_kernel_name()
     w = O.World(spheres=spheres_to_oracle(s))
     ref = O.render_counter(w, ocam, O.make_config(nx, ny, spp, **okw))
     return res, ref
@@ -78,12 +87,29 @@ def test_device_math_is_bit_exact(gpu_ctx):
 
 
 # ---- golden vectors ----------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["book", "two"])
+def _mesh_source():
+    """The golden 'mesh' scene (tests/golden/make_golden.py): four spheres tessellated 12x8."""
+    return R.Spheres(cx=[0, 0, -1, 1], cy=[0, -100.5, 0, 0], cz=[-1, -1, -1, -1], radius=[0.5, 100, 0.5, 0.5],
+                     kind=[0, 0, 2, 1], r=[.5, .5, .95, .8], g=[.5, .5, .95, .6], b=[.5, .5, .95, .2],
+                     param=[0, 0, 1.5, .15])
+
+
+@pytest.mark.parametrize("name,flavour", [("book", "brute"), ("book", "bvh"), ("two", "brute"), ("two", "bvh"),
+                                          ("mesh", "auto")])
 @pytest.mark.parametrize("depth", [16, 10])
-def test_golden_vectors(gpu_ctx, name, depth):
-    s, cam, _ = _scene(name, 32, 18)
-    gpu_ctx.upload_scene(s)
-    res = gpu_ctx.render(cam, R.make_config(32, 18, 4, max_depth=depth, seed=1), want_raycount=True)
+def test_golden_vectors(gpu_ctx, name, flavour, depth):
+    gpu_ctx.set_flags(FLAVOURS[flavour])
+    if name == "mesh":
+        src = _mesh_source()
+        gpu_ctx.upload_scene(triangles=R.Tessellate_Spheres(src, 12, 8), materials=src)
+        cam = R.BasicCamera()
+    else:
+        s, cam, _ = _scene(name, 32, 18)
+        gpu_ctx.upload_scene(s)
+    try:
+        res = gpu_ctx.render(cam, R.make_config(32, 18, 4, max_depth=depth, seed=1), want_raycount=True)
+    finally:
+        gpu_ctx.set_flags(0)
     key = "%s_d%d" % (name, depth)
     assert np.array_equal(res.raycount, GOLD[key + "_raycount"].astype(np.uint32))
     assert res.rays == int(GOLD[key + "_rays"])
@@ -92,16 +118,82 @@ def test_golden_vectors(gpu_ctx, name, depth):
 
 
 # ---- BASELINE configs --------------------------------------------------------------------------------
-def test_c1_book_400x225_10spp_depth10(gpu_ctx):
+@pytest.mark.parametrize("flavour", ["brute", "bvh"])
+def test_c1_book_400x225_10spp_depth10(gpu_ctx, flavour):
     """configs[0]: the CPU-runnable case, whole image against the oracle."""
-    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", 400, 225, 10, max_depth=10)
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", 400, 225, 10, flavour=flavour, max_depth=10)
     err = _compare(res, oa, o8, orc, cnt)
     print("C1 max|accum err| = %.3g, PSNR = %s" % (err, psnr_u8(res.rgb8, o8)))
 
 
-def test_c2_two_sphere_reduced(gpu_ctx):
-    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "two", 320, 180, 16)
+@pytest.mark.parametrize("flavour", ["brute", "bvh"])
+def test_c2_two_sphere_reduced(gpu_ctx, flavour):
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "two", 320, 180, 16, flavour=flavour)
     _compare(res, oa, o8, orc, cnt)
+
+
+def test_kernel_flavours_are_bit_identical(gpu_ctx):
+    """The BVH only culls; the exact tests and the shading are the brute-force kernel's, so the two
+    flavours must produce the same bits."""
+    a, _ = _both(gpu_ctx, "book", 160, 90, 6, flavour="brute")
+    b, _ = _both(gpu_ctx, "book", 160, 90, 6, flavour="bvh")
+    assert np.array_equal(a.raycount, b.raycount)
+    assert np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32))
+
+
+def test_c4_triangle_mesh_scene_1080p_256spp_sampled_pixels(gpu_ctx):
+    """configs[3]: the book scene's spheres tessellated as the reference's raster preview does
+    (main.zig:128-138: 150x150 / 30x30 / 20x20), 1920x1080, 256 spp; oracle on a random pixel subset."""
+    nx, ny, spp = 1920, 1080, 256
+    book = R.Random_Scene(11, 0)
+    tris = R.Tessellate_Spheres(book, 0, 0)
+    assert len(tris) == 285520
+    gpu_ctx.upload_scene(triangles=tris, materials=book)
+    res = gpu_ctx.render(R.book_camera(nx, ny), R.make_config(nx, ny, spp), want_raycount=True)
+    w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(book))
+    rng = np.random.default_rng(4)
+    pix = np.unique(rng.integers(0, nx * ny, 800)).astype(np.uint32)
+    oa, o8, orc, _ = O.render_counter(w, O.book_camera(nx, ny), O.make_config(nx, ny, spp), pixels=pix)
+    assert np.array_equal(res.raycount[pix], orc)
+    err = float(np.abs(res.accum[pix] - oa).max())
+    assert err <= TOL_ACCUM, err
+    assert psnr_u8(res.rgb8[pix], o8) >= MIN_PSNR
+    assert res.primary_rays == nx * ny * spp and res.rays == int(res.raycount.astype(np.uint64).sum())
+    assert np.all(np.isfinite(res.accum)) and res.accum.min() >= 0
+    print("C4 1080p/256spp: %d triangles, %d rays, kernel %.1f ms = %.0f Mrays/s, sampled max err %.3g"
+          % (len(tris), res.rays, res.kernel_ms, res.rays / res.kernel_ms / 1e3, err))
+
+
+def test_triangle_edge_cases(gpu_ctx):
+    """One triangle; a degenerate (zero-area) triangle beside real ones; a shared-edge hit (equal t on two
+    triangles: the lower index wins, as in list order)."""
+    mats = R.Spheres(cx=[0, 0], cy=[0, 0], cz=[0, 0], radius=[1, 1], kind=[0, 1], r=[.8, .9], g=[.3, .9], b=[.3, .9],
+                     param=[0, 0.0])
+    cases = [
+        R.Triangles([[-1, -1, -2]], [[1, -1, -2]], [[0, 1, -2]], [0]),
+        R.Triangles([[-1, -1, -2], [0, 0, -1.5], [-3, -1, -3]], [[1, -1, -2], [0, 0, -1.5], [3, -1, -3]],
+                    [[0, 1, -2], [0, 0, -1.5], [0, 2, -3]], [0, 1, 1]),
+        # a quad split along its diagonal, camera looking exactly at the diagonal for some pixels
+        R.Triangles([[-1, -1, -2], [-1, -1, -2]], [[1, -1, -2], [1, 1, -2]], [[1, 1, -2], [-1, 1, -2]], [0, 1]),
+    ]
+    for tris in cases:
+        gpu_ctx.upload_scene(triangles=tris, materials=mats)
+        res = gpu_ctx.render(R.BasicCamera(), R.make_config(64, 32, 6), want_raycount=True)
+        w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(mats))
+        oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(64, 32, 6))
+        _compare(res, oa, o8, orc, cnt)
+
+
+def test_large_random_sphere_scenes(gpu_ctx):
+    """Random_Scene at other sizes/seeds (deeper BVHs, other hollow-glass placements)."""
+    for half, seed in ((3, 5), (20, 7)):
+        s = R.Random_Scene(half, seed)
+        gpu_ctx.upload_scene(s)
+        cam, ocam = R.book_camera(120, 68), O.book_camera(120, 68)
+        res = gpu_ctx.render(cam, R.make_config(120, 68, 4), want_raycount=True)
+        w = O.World(spheres=spheres_to_oracle(s))
+        oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(120, 68, 4))
+        _compare(res, oa, o8, orc, cnt)
 
 
 @pytest.mark.parametrize("name,spp", [("two", 100), ("book", 100)])
@@ -185,8 +277,9 @@ def test_runs_are_deterministic(gpu_ctx):
     (48, 27, 3, {"seed": 0xDEADBEEFCAFEF00D}),   # 64-bit key
     (48, 27, 2, {"t_min": 0.0}),
 ])
-def test_edge_cases(gpu_ctx, nx, ny, spp, kw):
-    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", nx, ny, spp, **kw)
+@pytest.mark.parametrize("flavour", ["brute", "bvh"])
+def test_edge_cases(gpu_ctx, flavour, nx, ny, spp, kw):
+    res, (oa, o8, orc, cnt) = _both(gpu_ctx, "book", nx, ny, spp, flavour=flavour, **kw)
     _compare(res, oa, o8, orc, cnt)
 
 
@@ -240,6 +333,13 @@ def test_error_codes(gpu_ctx):
     s = R.Two_Sphere_Scene(); s.kind[0] = 7
     with pytest.raises(R.RtError):
         gpu_ctx.upload_scene(s)
+    tri = R.Triangles([[0, 0, -1]], [[1, 0, -1]], [[0, 1, -1]], [3])          # material index out of range
+    with pytest.raises(R.RtError):
+        gpu_ctx.upload_scene(triangles=tri, materials=R.Two_Sphere_Scene())
+    with pytest.raises(R.RtError):                                              # triangles need a material table
+        gpu_ctx.upload_scene(triangles=R.Triangles([[0, 0, -1]], [[1, 0, -1]], [[0, 1, -1]], [0]))
+    with pytest.raises(R.RtError):                                              # one kind of primitive per scene
+        gpu_ctx.upload_scene(R.Two_Sphere_Scene(), triangles=tri, materials=R.Two_Sphere_Scene())
 
 
 # ---- device-resident entry points (what bench.py and the multi-GPU driver use) ----------------------------
