@@ -89,26 +89,20 @@ def main():
     cam = R.book_camera(nx, ny) if scene == "book" else R.BasicCamera()
     ctx = R.Context(local_rank)
     ctx.upload_scene(spheres)
+    from raytrace_amd.distributed import HipRangeRenderer, render_sample_sharded
     npix = nx * ny
-    cfg = R.make_config(nx, ny, spp, max_depth=depth, seed=1, spp_begin=rank * spp, spp_end=(rank + 1) * spp,
-                        spp_total=spp * world)
+    renderer = HipRangeRenderer(ctx, cam, nx, ny, max_depth=depth, seed=1)
     accum = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")
-    rgb8 = torch.zeros(npix * 3, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
 
     kernel_ms = []
     rays_per_step = [0]
 
     def step(record):
-        accum.zero_()
-        rays, _prim, ms, _ = ctx.render_device(cam, cfg, accum.data_ptr(), 0, stream, want_stats=True)
-        if dist is not None:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            ctx.tonemap_device(accum.data_ptr(), npix, spp * world, 0, rgb8.data_ptr(), stream)
+        # zero accum -> trace this rank's samples [rank*spp, (rank+1)*spp) -> RCCL reduce -> tonemap on rank 0
+        res = render_sample_sharded(renderer, spp * world, dist, accum)
         if record:
-            kernel_ms.append(ms)
-            rays_per_step[0] = rays
+            kernel_ms.append(res.kernel_ms)
+            rays_per_step[0] = res.rays
 
     def fence():
         torch.cuda.synchronize()
@@ -150,7 +144,7 @@ def main():
                        "rays_per_step": rays_all, "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "rt_trace_spheres_kernel", "kernel_ms": k_ms,
+                         "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
                          "kernel_mrays_per_s": rays_per_step[0] / (k_ms * 1e-3) / 1e6,
                          "note": "FP32 vector roofline (not HBM/MFMA): algorithmic flops per ray are those of the "
