@@ -106,6 +106,10 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *
 /* What the last upload built (any pointer may be NULL). */
 int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
                   uint32_t *bvh_depth);
+/* Profiling aid, no reference counterpart: after a render with RT_FLAG_DEPTH_HISTOGRAM on a BVH scene,
+ * out = { wave traversal steps, lane traversal steps, wave exact-test iterations, lane exact-test
+ * iterations, wave shading passes, lanes shaded } -- lane/(64*wave) is the fill of each phase. */
+int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6]);
 /* Name of the trace kernel the last render launched (for profiles). */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 

@@ -47,7 +47,7 @@ class rt_stats(C.Structure):
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
-    "rt_scene_info", "rt_last_kernel_name",
+    "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill",
     "rt_render", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
     "rt_selftest_math",
@@ -89,6 +89,8 @@ def load():
     L.rt_upload_scene.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]
     L.rt_scene_info.restype = C.c_int
+    L.rt_debug_wave_fill.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rt_debug_wave_fill.restype = C.c_int
     L.rt_last_kernel_name.argtypes = [vp]
     L.rt_last_kernel_name.restype = C.c_char_p
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]

@@ -241,6 +241,15 @@ class Context:
         self._check(self._L.rt_scene_info(self._h, *[C.byref(x) for x in vals]), "rt_scene_info")
         return dict(zip(("n_spheres", "n_triangles", "n_bvh_nodes", "bvh_depth"), [int(x.value) for x in vals]))
 
+    def wave_fill(self):
+        """Fill of the BVH kernel's phases in the last RT_FLAG_DEPTH_HISTOGRAM render (profiling aid)."""
+        out = (C.c_uint64 * 6)()
+        self._check(self._L.rt_debug_wave_fill(self._h, out), "rt_debug_wave_fill")
+        ws, ls, wf, lf, wsh, lsh = [int(v) for v in out]
+        return {"wave_steps": ws, "lane_steps": ls, "traverse_fill": ls / max(1, 64 * ws),
+                "wave_exact_iters": wf, "lane_exact_iters": lf, "exact_fill": lf / max(1, 64 * wf),
+                "wave_shade_passes": wsh, "lanes_shaded": lsh, "shade_fill": lsh / max(1, 64 * wsh)}
+
     def last_kernel_name(self):
         return self._L.rt_last_kernel_name(self._h).decode()
 

@@ -28,6 +28,7 @@ struct rt_ctx {
     uint32_t     n_sph = 0, n_tri = 0, n_nodes = 0;
     int          bvh_depth = 0;
     TraceKernel  last_kernel = RT_K_BRUTE_SPHERES;
+    uint64_t     fill_counters[6] = { 0, 0, 0, 0, 0, 0 };
     // per-render scratch owned by the ctx
     uint32_t    *d_queue = nullptr;            // work-queue head
     unsigned long long *d_stats = nullptr;     // RT_STATS_WORDS
@@ -94,6 +95,12 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.n_items = p.tiles_x * tiles_y * 64u;
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
+    p.keep_traversing = 1;
+    p.force_global_scene = std::getenv("RT_HIP_GLOBAL_SCENE") ? 1u : 0u;
+    if (const char *e = std::getenv("RT_HIP_KEEP_TRAVERSING")) {    // tuning knob (1..64)
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) p.keep_traversing = (uint32_t)v;
+    }
 }
 
 // Spheres up to this count are traced by the brute-force kernel (one scalar-fed loop, no divergence);
@@ -140,6 +147,7 @@ int read_stats(rt_ctx *ctx, hipStream_t stream, rt_stats *stats)
     std::memset(stats, 0, sizeof *stats);
     stats->rays = h[0]; stats->primary_rays = h[1]; stats->kernel_ms = ms;
     for (int k = 0; k < 20; ++k) stats->rays_by_depth[k] = h[2 + k];
+    for (int k = 0; k < 6; ++k) ctx->fill_counters[k] = h[22 + k];
     return RT_OK;
 }
 
@@ -308,6 +316,13 @@ int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles,
     if (n_triangles) *n_triangles = ctx->n_tri;
     if (n_bvh_nodes) *n_bvh_nodes = ctx->n_nodes;
     if (bvh_depth) *bvh_depth = (uint32_t)ctx->bvh_depth;
+    return RT_OK;
+}
+
+int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6])
+{
+    if (!ctx || !out) return RT_E_ARG;
+    for (int k = 0; k < 6; ++k) out[k] = ctx->fill_counters[k];
     return RT_OK;
 }
 

@@ -16,6 +16,8 @@ struct TraceParams {
     uint32_t n_items;                       // work items = tiles * 64 (one per pixel slot)
     uint32_t q3;                            // 1: j = ny - jr (raytracer.zig:523)
     uint32_t n_prim;
+    uint32_t force_global_scene;            // BVH kernels: 1 = never stage the scene in LDS (test/tuning knob)
+    uint32_t keep_traversing;               // BVH kernels: leave the traversal loop when fewer lanes than this traverse
 };
 
 // Device scene.  16-byte records so one scalar/vector load fetches a whole record.
@@ -38,8 +40,10 @@ struct DeviceScene {
 
 enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANGLES = 2 };
 
-// stats buffer layout (unsigned long long[]): [0] rays, [1] primary rays, [2..21] rays by depth
-enum { RT_STATS_WORDS = 22 };
+// stats buffer layout (unsigned long long[]): [0] rays, [1] primary rays, [2..21] rays by depth,
+// [22..27] BVH wave-fill counters of histogram builds: wave/lane traversal steps, wave/lane exact-test
+// iterations, wave/lane shading passes
+enum { RT_STATS_WORDS = 28 };
 
 hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const DeviceScene &s, float *accum_sum,
                            uint32_t *raycount, uint32_t *queue, unsigned long long *stats,

@@ -24,6 +24,8 @@
 #include "rt_kernels.h"
 #include "rt_device.h"
 
+#include <type_traits>
+
 using namespace rtd;
 
 namespace {
@@ -56,11 +58,9 @@ struct Surface {          // HitRecord (raytracer.zig:31-36) with the material f
     f3       albedo;
 };
 
-// trace's per-sample prologue: raytracer.zig:537-539 and camera.zig:16/:39
-__device__ __forceinline__ void camera_ray(const TraceParams &P, Lane &L)
+// trace's per-sample prologue: raytracer.zig:537-539 and camera.zig:16/:39.  r = Philox block 0 of the sample.
+__device__ __forceinline__ void camera_ray(const TraceParams &P, Lane &L, const uint32_t r[4])
 {
-    uint32_t r[4];
-    philox4x32_10(L.pix, L.sample, 0u, 0u, P.key0, P.key1, r);
     const float u = ((float)L.i + u32_to_unit_float(r[0])) / (float)P.nx;
     const float v = ((float)L.j + u32_to_unit_float(r[1])) / (float)P.ny;
     f3 dir = mk(P.ll[0], P.ll[1], P.ll[2]) + u * mk(P.hz[0], P.hz[1], P.hz[2]) + v * mk(P.vt[0], P.vt[1], P.vt[2]);
@@ -71,63 +71,50 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Lane &L)
     L.depth = 0;
 }
 
-// sky, raytracer.zig:569-571
-__device__ __forceinline__ void shade_miss(Lane &L, float a_dd)
+// Material.scatter (raytracer.zig:407-414) for one lane.  unit = normalize(direction) (unused for
+// lambertian), r = Philox block depth+1.  Returns true when the path continues with the scattered ray
+// in L.o/L.d.
+__device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, float len_d, const uint32_t r[4])
 {
-    const float len_d = sqrtf(a_dd);
-    const f3 unit = L.d / len_d;
-    const float tt = 0.5f * (unit.y + 1.0f);
-    const f3 sky = mk((1.0f - tt) + tt * 0.5f, (1.0f - tt) + tt * 0.7f, (1.0f - tt) + tt * 1.0f);
-    L.col = L.col + L.thr * sky;
-}
-
-// Material.scatter (raytracer.zig:407-414) for one lane.  Returns true when the path continues
-// with the scattered ray in L.o/L.d.
-__device__ __forceinline__ bool shade_hit(const TraceParams &P, Lane &L, const Surface &S, float a_dd)
-{
-    const float len_d = sqrtf(a_dd);                 // vector.zig:10-13 length(direction)
     const f3 p = S.p, n = S.n;
-    uint32_t r[4];
-    philox4x32_10(L.pix, L.sample, L.depth + 1u, 0u, P.key0, P.key1, r);
-
     f3 dir;
-    if (S.kind == K_DIELECTRIC) {                     // Dielectric.scatter, raytracer.zig:469-499
-        const float param = S.param;
-        const f3 unit = L.d / len_d;
-        const float dn_u = dot(unit, n);
-        const f3 reflected = unit - (2.0f * dn_u) * n;             // :450-452
-        const float ddn = dot(L.d, n);
-        f3 on; float ni_over_nt, cosine;
-        if (ddn > 0) { on = -n; ni_over_nt = param; cosine = (param * ddn) / len_d; }
-        else { on = n; ni_over_nt = 1.0f / param; cosine = (-ddn) / len_d; }
-        const float dt = dot(unit, on);                            // refract, :453-463
-        const float disc = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
-        float reflect_prob = 1.0f;
-        f3 refracted = mk(0.0f, 0.0f, 0.0f);
-        if (disc > 0) {
-            const float sq = sqrtf(disc);
-            const f3 w = unit - dt * on;   // uv - n*splat(dt)
-            refracted = mk(ni_over_nt * w.x - on.x * sq, ni_over_nt * w.y - on.y * sq, ni_over_nt * w.z - on.z * sq);
-            float r0 = (1.0f - param) / (1.0f + param);            // schlick, :464-468
-            r0 = r0 * r0;
-            reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
-        }
-        dir = (u32_to_unit_float(r[0]) < reflect_prob) ? reflected : refracted;   // :492-496
-    } else {
-        // random_in_unit_sphere, raytracer.zig:574-578
+    if (S.kind == K_LAMBERTIAN) {
+        // random_in_unit_sphere, raytracer.zig:574-578; Lambertian.scatter, :438-445
         const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
         const f3 cn = cube / sqrtf(dot(cube, cube));
         const float cb = cbrt_f32(u32_to_unit_float(r[3]));
         const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
-        if (S.kind == K_LAMBERTIAN) {                 // Lambertian.scatter, raytracer.zig:438-445
-            const f3 target = (p + n) + rius;
-            dir = target - p;
-        } else {                                      // Metal.scatter, raytracer.zig:423-433
-            const f3 unit = L.d / len_d;
-            const float dn_u = dot(unit, n);
-            const f3 reflected = unit - (2.0f * dn_u) * n;
+        const f3 target = (p + n) + rius;
+        dir = target - p;
+    } else {
+        const float dn_u = dot(unit, n);
+        const f3 reflected = unit - (2.0f * dn_u) * n;             // reflect, :420-422 / :450-452
+        if (S.kind == K_METAL) {                                   // Metal.scatter, :423-433
+            const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
+            const f3 cn = cube / sqrtf(dot(cube, cube));
+            const float cb = cbrt_f32(u32_to_unit_float(r[3]));
+            const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
             dir = reflected + S.param * rius;
-            if (!(dot(dir, n) > 0)) return false;     // absorbed: the path returns black
+            if (!(dot(dir, n) > 0)) return false;                  // absorbed: the path returns black
+        } else {                                                   // Dielectric.scatter, :469-499
+            const float param = S.param;
+            const float ddn = dot(L.d, n);
+            f3 on; float ni_over_nt, cosine;
+            if (ddn > 0) { on = -n; ni_over_nt = param; cosine = (param * ddn) / len_d; }
+            else { on = n; ni_over_nt = 1.0f / param; cosine = (-ddn) / len_d; }
+            const float dt = dot(unit, on);                        // refract, :453-463
+            const float disc = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
+            float reflect_prob = 1.0f;
+            f3 refracted = mk(0.0f, 0.0f, 0.0f);
+            if (disc > 0) {
+                const float sq = sqrtf(disc);
+                const f3 w = unit - dt * on;                       // uv - n*splat(dt)
+                refracted = mk(ni_over_nt * w.x - on.x * sq, ni_over_nt * w.y - on.y * sq, ni_over_nt * w.z - on.z * sq);
+                float r0 = (1.0f - param) / (1.0f + param);        // schlick, :464-468
+                r0 = r0 * r0;
+                reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
+            }
+            dir = (u32_to_unit_float(r[0]) < reflect_prob) ? reflected : refracted;   // :492-496
         }
     }
     L.thr = L.thr * S.albedo;
@@ -176,12 +163,13 @@ __device__ __forceinline__ void triangle_exact(f3 v0, f3 v1, f3 v2, uint32_t pri
     if ((t < T_MAX) && (t > t_min) && ((t < best_t) || (t == best_t && prim < best))) { best_t = t; best = prim; }
 }
 
-// slab test of one padded box against [t_lo, t_hi]; tn = entry distance
-__device__ __forceinline__ bool box_hit(f3 lo, f3 hi, f3 o, f3 inv, float t_lo, float t_hi, float &tn)
+// slab test of one padded box in FMA form: plane distance = lo*inv - o*inv (noi = -(o*inv)).  Only
+// culls, so it may round differently from the CPU: the padding covers it (rt_bvh.hpp).
+__device__ __forceinline__ bool box_hit_fma(f3 lo, f3 hi, f3 inv, f3 noi, float t_lo, float t_hi, float &tn)
 {
-    const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-    const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-    const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+    const float x0 = __builtin_fmaf(lo.x, inv.x, noi.x), x1 = __builtin_fmaf(hi.x, inv.x, noi.x);
+    const float y0 = __builtin_fmaf(lo.y, inv.y, noi.y), y1 = __builtin_fmaf(hi.y, inv.y, noi.y);
+    const float z0 = __builtin_fmaf(lo.z, inv.z, noi.z), z1 = __builtin_fmaf(hi.z, inv.z, noi.z);
     const float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
     const float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_hi));
     tn = n;
@@ -190,22 +178,203 @@ __device__ __forceinline__ bool box_hit(f3 lo, f3 hi, f3 o, f3 inv, float t_lo, 
 
 enum { KIND_BRUTE_SPHERES = 0, KIND_BVH_SPHERES = 1, KIND_BVH_TRIANGLES = 2 };
 
-template <int KIND, int STACK, bool HIST>
-__global__ __launch_bounds__(BLOCK) void rt_trace_kernel(
-    const TraceParams P,
-    const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
-    const float4 *__restrict__ albedo, const float4 *__restrict__ bvh,
-    float *__restrict__ accum, uint32_t *__restrict__ raycount,
+struct Outputs {
+    float              *accum;
+    uint32_t           *raycount;
+    uint32_t           *queue;
+    unsigned long long  my_rays, my_primary;
+};
+
+// A lane without a ray moves to its next (pixel, sample): the next sample of its pixel, or -- when the
+// pixel is done -- it writes the pixel out and pulls the next pixel from the global queue (one
+// wave-aggregated atomic for all lanes of the wave that need one).  Render's loops, raytracer.zig:521-528,
+// and trace's, :536-541.  Returns true when a camera ray is to be generated for (L.pix, L.sample).
+__device__ __forceinline__ bool advance(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane)
+{
+    if (L.sample >= P.spp_end) {
+        if (L.pix != NOPIX) {                         // pixel finished: this lane is its only writer
+            float *dst = O.accum + 3ull * L.pix;
+            dst[0] += L.col.x; dst[1] += L.col.y; dst[2] += L.col.z;
+            if (O.raycount) O.raycount[L.pix] += L.nrays;
+            O.my_rays += L.nrays;
+            L.pix = NOPIX;
+        }
+        const unsigned long long m = __ballot(1);
+        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(O.queue, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);  // leader = first active lane
+        const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (item >= P.n_items) {
+            alive = false;
+        } else {
+            // item -> pixel: 8x8 tiles, row-major inside a tile, so a wave starts on one coherent tile
+            const uint32_t tile = item >> 6, within = item & 63u;
+            const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+            const uint32_t i = P.x0 + tx * 8u + (within & 7u);
+            const uint32_t jr = P.y0 + ty * 8u + (within >> 3);
+            if (i < P.x1 && jr < P.y1) {
+                L.pix = jr * P.nx + i;                // raytracer.zig:521-528 output index
+                L.i = i;
+                L.j = P.q3 ? (P.ny - jr) : (P.ny - 1u - jr);   // raytracer.zig:523
+                L.sample = P.spp_begin;
+                L.col = mk(0, 0, 0);
+                L.nrays = 0;
+            }
+        }
+    }
+    return L.pix != NOPIX && L.sample < P.spp_end;
+}
+
+// Everything between two world.hit calls of a lane: the rest of color() after the hit test
+// (raytracer.zig:555-571) for a lane whose ray is resolved (best/best_t), and the next ray of the lane --
+// the scattered ray, or the camera ray of its next sample when the path ended.  The two cases need
+// different Philox blocks but never both in one lane, so ONE Philox evaluation serves the whole wave.
+// A metal-absorbed lane (1 in 10^4 rays) simply gets its camera ray in the next pass.
+template <bool HIST, class SurfaceFn>
+__device__ __forceinline__ void shade_and_spawn(const TraceParams &P, Lane &L, bool &alive, bool &has_ray, Outputs &O,
+                                                uint32_t lane, float a, float best_t, uint32_t best,
+                                                uint32_t *s_hist, SurfaceFn fetch_surface)
+{
+    bool scatter = false;
+    f3 unit = mk(0, 0, 0);
+    float len_d = 1.0f;
+    Surface S;
+    S.kind = K_LAMBERTIAN;
+    if (has_ray) {
+        L.nrays += 1;
+        if (HIST) atomicAdd(&s_hist[L.depth < 19u ? L.depth : 19u], 1u);
+        len_d = sqrtf(a);                             // vector.zig:10-13 length(direction)
+        const bool hit = best != NOHIT;
+        if (hit && L.depth <= P.max_depth) {          // raytracer.zig:556-558: the cap is tested after the hit
+            S.p = L.o + best_t * L.d;                 // ray.zig:10-12
+            fetch_surface(best, S);
+            scatter = true;
+        }
+        if (!hit || S.kind != K_LAMBERTIAN) unit = L.d / len_d;    // normalize: three true divides
+        if (!hit) {                                   // sky, raytracer.zig:569-571
+            const float tt = 0.5f * (unit.y + 1.0f);
+            const f3 sky = mk((1.0f - tt) + tt * 0.5f, (1.0f - tt) + tt * 0.7f, (1.0f - tt) + tt * 1.0f);
+            L.col = L.col + L.thr * sky;
+        }
+        if (!scatter) { L.sample += 1; has_ray = false; }
+    }
+    bool gen = false;
+    if (!has_ray && alive) gen = advance(P, L, alive, O, lane);
+    if (scatter || gen) {
+        uint32_t r[4];
+        philox4x32_10(L.pix, L.sample, scatter ? L.depth + 1u : 0u, 0u, P.key0, P.key1, r);
+        if (gen) {
+            camera_ray(P, L, r);
+            has_ray = true;
+            O.my_primary += 1;
+        } else if (!scatter_ray(L, S, unit, len_d, r)) {
+            L.sample += 1; has_ray = false;
+        }
+    }
+}
+
+__device__ __forceinline__ void finish(const Outputs &O, unsigned long long *stats, uint32_t *s_hist, bool hist)
+{
+    atomicAdd(&stats[0], O.my_rays);
+    atomicAdd(&stats[1], O.my_primary);
+    if (hist) {
+        __syncthreads();
+        if (threadIdx.x < 20) atomicAdd(&stats[2 + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    }
+}
+
+// ---- brute force: small sphere scenes ------------------------------------------------------------------
+template <bool HIST>
+__global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
+    const TraceParams P, const float4 *__restrict__ geom, const float4 *__restrict__ aux,
+    const float4 *__restrict__ albedo, float *__restrict__ accum, uint32_t *__restrict__ raycount,
     uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
 {
-    constexpr bool USE_BVH = KIND != KIND_BRUTE_SPHERES;
     __shared__ uint32_t s_hist[20];
-    __shared__ uint32_t s_stack[USE_BVH ? STACK * BLOCK : 1];
-    __shared__ uint32_t s_cand[USE_BVH ? CAND * BLOCK : 1];
     if (HIST) {
         if (threadIdx.x < 20) s_hist[threadIdx.x] = 0;
         __syncthreads();
     }
+    const uint32_t lane = threadIdx.x & 63u;
+    Lane L;
+    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
+    L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = P.spp_end; L.depth = 0; L.nrays = 0;
+    bool alive = true, has_ray = false;
+    Outputs O{ accum, raycount, queue, 0ull, 0ull };
+
+    float a = 1.0f, best_t = T_MAX;
+    uint32_t best = NOHIT;
+    for (;;) {
+        // resolve the rays of the previous iteration and give every lane its next ray
+        shade_and_spawn<HIST>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+            const float4 g = geom[prim], ax = aux[prim], al = albedo[prim];
+            S.n = (S.p - mk(g.x, g.y, g.z)) / ax.x;                // raytracer.zig:60
+            S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
+        });
+        if (__ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
+
+        // world.hit: closest root over all spheres in list order (raytracer.zig:92-113).  Lanes without a
+        // ray run the loop on dummy data.
+        a = dot(L.d, L.d);
+        best_t = T_MAX;
+        best = NOHIT;
+        for (uint32_t s = 0; s < P.n_prim; ++s) {
+            const float4 g = geom[s];                 // wave-uniform address -> scalar load
+            const f3 oc = mk(L.o.x - g.x, L.o.y - g.y, L.o.z - g.z);
+            const float b = dot(oc, L.d);
+            const float c = dot(oc, oc) - g.w;
+            const float disc = b * b - a * c;
+            if (disc > 0) {
+                const float sq = sqrtf(disc);
+                float t = (-b - sq) / a;
+                if (!((t < best_t) && (t > P.t_min))) t = (-b + sq) / a;
+                if ((t < best_t) && (t > P.t_min)) { best_t = t; best = s; }
+            }
+        }
+    }
+    finish(O, stats, s_hist, HIST);
+}
+
+// ---- BVH traversal: spheres or triangles ----------------------------------------------------------------
+// Traversal and shading are decoupled: a lane is either TRAVERSING (node != DONE) or waiting to be shaded.
+// The wave keeps taking traversal steps while at least KEEP_TRAVERSING lanes still traverse; below that it
+// runs the exact tests, shades the finished lanes and gives them their next ray (bounce or new camera
+// ray), and they rejoin the traversal at the root beside the lanes that are still on their way.  Lanes
+// therefore do not idle for the wave's slowest ray.
+
+//
+// LDSN = true (small scenes, e.g. the book scene): the whole scene is staged in LDS once per workgroup --
+// BVH nodes re-strided from 64 to 80 bytes (20 dwords, so the 16-byte reads of 16 lanes at random nodes spread
+// over all bank quads instead of 4) and the sphere records -- and stack/queue entries shrink to 16 bits.
+// LDSN = false (large scenes, e.g. 285k triangles): nodes and primitives are read from global memory
+// through L1/L2.
+constexpr int LDS_NODE_STRIDE = 5;                    // float4 per node in LDS (4 used + 1 pad)
+
+template <int KIND, int STACK, bool HIST, bool LDSN, int NT>
+__global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
+    const TraceParams P,
+    const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
+    const float4 *__restrict__ albedo, const float4 *__restrict__ bvh, const uint32_t n_nodes,
+    float *__restrict__ accum, uint32_t *__restrict__ raycount,
+    uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
+{
+    typedef typename std::conditional<LDSN, uint16_t, uint32_t>::type idx_t;
+    constexpr int BLOCK = NT;
+    __shared__ uint32_t s_hist[20];
+    __shared__ idx_t s_stack[STACK * BLOCK];          // [entry][thread]: a wave's accesses are conflict-free
+    __shared__ idx_t s_cand[CAND * BLOCK];
+    extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
+    const float4 *s_geom = s_scene + (LDSN ? n_nodes * LDS_NODE_STRIDE : 0u);
+    if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
+    if (LDSN) {
+        for (uint32_t k = threadIdx.x; k < n_nodes * 4u; k += NT)
+            s_scene[(k >> 2) * LDS_NODE_STRIDE + (k & 3u)] = bvh[k];
+        if (KIND == KIND_BVH_SPHERES)
+            for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
+                s_scene[n_nodes * LDS_NODE_STRIDE + k] = geom[k];
+    }
+    if (HIST || LDSN) __syncthreads();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
 
@@ -213,169 +382,115 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_kernel(
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
     L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = P.spp_end; L.depth = 0; L.nrays = 0;
     bool alive = true, has_ray = false;
-    unsigned long long my_rays = 0, my_primary = 0;
+    Outputs O{ accum, raycount, queue, 0ull, 0ull };
+
+    // traversal state of the lane's current ray
+    uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
+    float best_t = T_MAX, a = 1.0f;
+    f3 inv = mk(1, 1, 1), noi = mk(0, 0, 0);
+
+    // HIST builds also count how well the wave is filled in each phase (profiling aid; lane 0 of a wave
+    // counts wave-level events, every lane its own)
+    unsigned long long c_wsteps = 0, c_lsteps = 0, c_wflush = 0, c_lflush = 0, c_wshade = 0, c_lshade = 0;
+
+    // exact primitive tests for every queued candidate of every lane (wave-wide batch)
+    auto flush = [&]() {
+        for (uint32_t k = 0; __ballot(k < ncand) != 0ull; ++k) {
+            if (HIST) c_wflush += 1;
+            if (k < ncand) {
+                if (HIST) c_lflush += 1;
+                const uint32_t prim = s_cand[k * BLOCK + tid];
+                if (KIND == KIND_BVH_SPHERES) {
+                    sphere_exact(LDSN ? s_geom[prim] : geom[prim], prim, L, a, P.t_min, best_t, best);
+                } else {
+                    const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
+                    triangle_exact(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), prim, L,
+                                   P.t_min, best_t, best);
+                }
+            }
+        }
+        ncand = 0;
+    };
 
     for (;;) {
-        if (!has_ray && alive) {
-            if (L.sample >= P.spp_end) {
-                if (L.pix != NOPIX) {                 // pixel finished: this lane is its only writer
-                    float *dst = accum + 3ull * L.pix;
-                    dst[0] += L.col.x; dst[1] += L.col.y; dst[2] += L.col.z;
-                    if (raycount) raycount[L.pix] += L.nrays;
-                    my_rays += L.nrays;
-                    L.pix = NOPIX;
-                }
-                // wave-aggregated dequeue: one atomic for all lanes of the wave that need a pixel
-                const unsigned long long m = __ballot(1);
-                const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(queue, (uint32_t)__popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);   // leader = first active lane
-                const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (item >= P.n_items) {
-                    alive = false;
-                } else {
-                    // item -> pixel: 8x8 tiles, row-major inside a tile, so a wave starts on one tile
-                    const uint32_t tile = item >> 6, within = item & 63u;
-                    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-                    const uint32_t i = P.x0 + tx * 8u + (within & 7u);
-                    const uint32_t jr = P.y0 + ty * 8u + (within >> 3);
-                    if (i < P.x1 && jr < P.y1) {
-                        L.pix = jr * P.nx + i;        // raytracer.zig:521-528 output index
-                        L.i = i;
-                        L.j = P.q3 ? (P.ny - jr) : (P.ny - 1u - jr);   // raytracer.zig:523
-                        L.sample = P.spp_begin;
-                        L.col = mk(0, 0, 0);
-                        L.nrays = 0;
-                    }
-                }
-            }
-            if (L.pix != NOPIX && L.sample < P.spp_end) {
-                camera_ray(P, L);
-                has_ray = true;
-                my_primary += 1;
-            }
-        }
-        if (__ballot(alive) == 0ull) break;           // every lane has drained the queue
-
-        // ---- world.hit ---------------------------------------------------------------------------
-        const float a = dot(L.d, L.d);
-        float best_t = T_MAX;
-        uint32_t best = NOHIT;
-
-        if (KIND == KIND_BRUTE_SPHERES) {
-            // closest root over all spheres in list order (raytracer.zig:92-113).  Lanes without a
-            // ray run the loop on dummy data.
-            for (uint32_t s = 0; s < P.n_prim; ++s) {
-                const float4 g = geom[s];             // wave-uniform address -> scalar load
-                const f3 oc = mk(L.o.x - g.x, L.o.y - g.y, L.o.z - g.z);
-                const float b = dot(oc, L.d);
-                const float c = dot(oc, oc) - g.w;
-                const float disc = b * b - a * c;
-                if (disc > 0) {
-                    const float sq = sqrtf(disc);
-                    float t = (-b - sq) / a;
-                    if (!((t < best_t) && (t > P.t_min))) t = (-b + sq) / a;
-                    if ((t < best_t) && (t > P.t_min)) { best_t = t; best = s; }
-                }
-            }
-        } else {
-            // per-lane BVH traversal; every iteration of the loop is an inner-node visit for every
-            // lane that still traverses, leaves are only queued.
-            f3 dd = L.d;                              // guard the reciprocal against zero components
-            if (fabsf(dd.x) < 1e-30f) dd.x = copysignf(1e-30f, dd.x);
-            if (fabsf(dd.y) < 1e-30f) dd.y = copysignf(1e-30f, dd.y);
-            if (fabsf(dd.z) < 1e-30f) dd.z = copysignf(1e-30f, dd.z);
-            const f3 inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
-            uint32_t node = has_ray ? 0u : DONE;
-            uint32_t sp = 0, ncand = 0;
-
-            auto flush = [&]() {
-                for (uint32_t k = 0; __ballot(k < ncand) != 0ull; ++k) {
-                    if (k < ncand) {
-                        const uint32_t prim = s_cand[k * BLOCK + tid];
-                        if (KIND == KIND_BVH_SPHERES) {
-                            sphere_exact(geom[prim], prim, L, a, P.t_min, best_t, best);
-                        } else {
-                            const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
-                            triangle_exact(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), prim, L,
-                                           P.t_min, best_t, best);
-                        }
-                    }
-                }
-                ncand = 0;
-            };
-
-            while (__ballot(node != DONE) != 0ull) {
-                if (node != DONE) {
-                    const float4 q0 = bvh[4u * node], q1 = bvh[4u * node + 1u], q2 = bvh[4u * node + 2u],
-                                 q3 = bvh[4u * node + 3u];
-                    float tn0, tn1;
-                    const bool h0 = box_hit(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), L.o, inv, P.t_min, best_t, tn0);
-                    const bool h1 = box_hit(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), L.o, inv, P.t_min, best_t, tn1);
-                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                    const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
-                    if (h0 && l0) { s_cand[ncand * BLOCK + tid] = c0 & ~LEAF_BIT; ncand += 1; }
-                    if (h1 && l1) { s_cand[ncand * BLOCK + tid] = c1 & ~LEAF_BIT; ncand += 1; }
-                    const bool v0 = h0 && !l0, v1 = h1 && !l1;
-                    if (v0 && v1) {                   // descend into the nearer child, stack the other
-                        const bool first0 = tn0 <= tn1;
-                        s_stack[sp * BLOCK + tid] = first0 ? c1 : c0;
-                        sp += 1;
-                        node = first0 ? c0 : c1;
-                    } else if (v0) {
-                        node = c0;
-                    } else if (v1) {
-                        node = c1;
-                    } else if (sp > 0) {
-                        sp -= 1;
-                        node = s_stack[sp * BLOCK + tid];
+        // ---- lanes whose traversal is complete: exact tests, shade, next ray --------------------------
+        if (__ballot(node == DONE && (has_ray || alive)) != 0ull) {
+            flush();                                  // also tightens best_t of the lanes still traversing
+            if (HIST) c_wshade += 1;
+            if (node == DONE) {
+                if (HIST && has_ray) c_lshade += 1;
+                shade_and_spawn<HIST>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+                    uint32_t mat;
+                    if (KIND == KIND_BVH_TRIANGLES) {
+                        const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
+                        const f3 v0 = mk(p0.x, p0.y, p0.z);
+                        const f3 e1 = mk(p1.x, p1.y, p1.z) - v0, e2 = mk(p2.x, p2.y, p2.z) - v0;
+                        const f3 cr = cross(e1, e2);
+                        S.n = cr / sqrtf(dot(cr, cr));
+                        mat = __float_as_uint(p0.w);
                     } else {
-                        node = DONE;
+                        const float4 g = LDSN ? s_geom[prim] : geom[prim];
+                        mat = prim;
+                        S.n = (S.p - mk(g.x, g.y, g.z)) / aux[mat].x;   // raytracer.zig:60
                     }
+                    const float4 ax = aux[mat], al = albedo[mat];
+                    S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
+                });
+                if (has_ray) {                        // start the new ray at the root
+                    a = dot(L.d, L.d);
+                    f3 dd = L.d;                      // guard the reciprocal against zero components
+                    if (fabsf(dd.x) < 1e-30f) dd.x = copysignf(1e-30f, dd.x);
+                    if (fabsf(dd.y) < 1e-30f) dd.y = copysignf(1e-30f, dd.y);
+                    if (fabsf(dd.z) < 1e-30f) dd.z = copysignf(1e-30f, dd.z);
+                    inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
+                    noi = mk(-(L.o.x * inv.x), -(L.o.y * inv.y), -(L.o.z * inv.z));
+                    node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                 }
-                // batch the exact tests: run them for the whole wave when some lane's queue is nearly full
-                if (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) flush();
             }
-            flush();
         }
+        if (__ballot(alive || has_ray) == 0ull) break;         // queue drained and nothing in flight
 
-        if (has_ray) {
-            L.nrays += 1;
-            if (HIST) atomicAdd(&s_hist[L.depth < 19u ? L.depth : 19u], 1u);
-            bool cont = false;
-            if (best == NOHIT) {
-                shade_miss(L, a);
-            } else if (L.depth <= P.max_depth) {      // raytracer.zig:556-558: the cap is tested after the hit
-                Surface S;
-                S.p = L.o + best_t * L.d;             // ray.zig:10-12
-                uint32_t mat;
-                if (KIND == KIND_BVH_TRIANGLES) {
-                    const float4 p0 = tri[3u * best], p1 = tri[3u * best + 1u], p2 = tri[3u * best + 2u];
-                    const f3 v0 = mk(p0.x, p0.y, p0.z);
-                    const f3 e1 = mk(p1.x, p1.y, p1.z) - v0, e2 = mk(p2.x, p2.y, p2.z) - v0;
-                    const f3 cr = cross(e1, e2);
-                    S.n = cr / sqrtf(dot(cr, cr));
-                    mat = __float_as_uint(p0.w);
+        // ---- traversal steps: every iteration is an inner-node visit for every traversing lane; hit
+        //      leaves are only queued.
+        for (;;) {
+            if (HIST) c_wsteps += 1;
+            if (node != DONE) {
+                if (HIST) c_lsteps += 1;
+                const float4 *nd = LDSN ? s_scene + node * LDS_NODE_STRIDE : bvh + 4u * node;
+                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                float tn0, tn1;
+                const bool h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
+                const bool h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
+                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
+                if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
+                if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
+                const bool v0 = h0 && !l0, v1 = h1 && !l1;
+                if (v0 && v1) {                       // descend into the nearer child, stack the other
+                    const bool first0 = tn0 <= tn1;
+                    s_stack[sp * BLOCK + tid] = (idx_t)(first0 ? c1 : c0);
+                    sp += 1;
+                    node = first0 ? c0 : c1;
+                } else if (v0) {
+                    node = c0;
+                } else if (v1) {
+                    node = c1;
+                } else if (sp > 0) {
+                    sp -= 1;
+                    node = s_stack[sp * BLOCK + tid];
                 } else {
-                    const float4 g = geom[best];
-                    mat = best;
-                    const float radius = aux[mat].x;
-                    S.n = (S.p - mk(g.x, g.y, g.z)) / radius;      // raytracer.zig:60
+                    node = DONE;
                 }
-                const float4 ax = aux[mat], al = albedo[mat];
-                S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
-                cont = shade_hit(P, L, S, a);
             }
-            if (!cont) { L.sample += 1; has_ray = false; }
+            // a queue is nearly full somewhere: run the exact tests for the whole wave
+            if (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) flush();
+            if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
         }
     }
-
-    atomicAdd(&stats[0], my_rays);
-    atomicAdd(&stats[1], my_primary);
+    finish(O, stats, s_hist, HIST);
     if (HIST) {
-        __syncthreads();
-        if (threadIdx.x < 20) atomicAdd(&stats[2 + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+        if (lane == 0) { atomicAdd(&stats[22], c_wsteps); atomicAdd(&stats[24], c_wflush); atomicAdd(&stats[26], c_wshade); }
+        atomicAdd(&stats[23], c_lsteps); atomicAdd(&stats[25], c_lflush); atomicAdd(&stats[27], c_lshade);
     }
 }
 
@@ -409,20 +524,47 @@ __global__ void rt_selftest_kernel(uint32_t n, const float *a, const float *b, f
     philox_out[4 * k + 2] = r[2]; philox_out[4 * k + 3] = r[3];
 }
 
-template <int KIND, int STACK, bool HIST>
-hipError_t launch_one(const TraceParams &p, const DeviceScene &s, float *accum_sum, uint32_t *raycount,
-                      uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
+static long long grid_for(const void *kern, const TraceParams &p, int num_cus, int threads, size_t dyn_lds)
 {
-    auto kern = rt_trace_kernel<KIND, STACK, HIST>;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    long long want = ((long long)p.n_items + BLOCK - 1) / BLOCK;    // no more blocks than work
+    long long want = ((long long)p.n_items + threads - 1) / threads;    // no more blocks than work
     long long grid = (long long)num_cus * per_cu;
     if (grid > want) grid = want;
-    if (grid < 1) grid = 1;
+    return grid < 1 ? 1 : grid;
+}
+
+// LDS-resident scene: nodes at 80 bytes + sphere records must fit beside the per-thread stack/queue
+static size_t lds_scene_bytes(const DeviceScene &s, bool spheres)
+{
+    return (size_t)s.n_nodes * LDS_NODE_STRIDE * 16 + (spheres ? (size_t)s.n_prim * 16 : 0);
+}
+static bool fits_lds(const DeviceScene &s, bool spheres)
+{
+    return s.bvh_depth <= 16 && s.n_nodes < 65536u && s.n_prim < 32768u && lds_scene_bytes(s, spheres) <= 40 * 1024;
+}
+
+template <int KIND, int STACK, bool HIST, bool LDSN, int NT>
+hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, uint32_t *raycount,
+                      uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
+{
+    auto kern = rt_trace_bvh_kernel<KIND, STACK, HIST, LDSN, NT>;
+    const size_t dyn = LDSN ? lds_scene_bytes(s, KIND == KIND_BVH_SPHERES) : 0;
+    const long long grid = grid_for((const void *)kern, p, num_cus, NT, dyn);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), dyn, stream,
+                       p, s.geom, s.tri, s.aux, s.albedo, s.bvh, s.n_nodes, accum_sum, raycount, queue, stats);
+    return hipGetLastError();
+}
+
+template <bool HIST>
+hipError_t launch_brute(const TraceParams &p, const DeviceScene &s, float *accum_sum, uint32_t *raycount,
+                        uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
+{
+    auto kern = rt_trace_brute_kernel<HIST>;
+    const long long grid = grid_for((const void *)kern, p, num_cus, BLOCK, 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), 0, stream,
-                       p, s.geom, s.tri, s.aux, s.albedo, s.bvh, accum_sum, raycount, queue, stats);
+                       p, s.geom, s.aux, s.albedo, accum_sum, raycount, queue, stats);
     return hipGetLastError();
 }
 
@@ -441,14 +583,22 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
                            uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
                            bool histogram, int num_cus, hipStream_t stream)
 {
-#define RT_LAUNCH(KIND, STACK)                                                                            \
-    (histogram ? launch_one<KIND, STACK, true>(p, s, accum_sum, raycount, queue, stats, num_cus, stream)  \
-               : launch_one<KIND, STACK, false>(p, s, accum_sum, raycount, queue, stats, num_cus, stream))
-    if (which == RT_K_BRUTE_SPHERES) return RT_LAUNCH(KIND_BRUTE_SPHERES, 1);
+#define RT_ARGS p, s, accum_sum, raycount, queue, stats, num_cus, stream
+    if (which == RT_K_BRUTE_SPHERES) return histogram ? launch_brute<true>(RT_ARGS) : launch_brute<false>(RT_ARGS);
     if (s.bvh_depth > 32 || !s.bvh) return hipErrorInvalidValue;
-    if (which == RT_K_BVH_SPHERES) return s.bvh_depth <= 16 ? RT_LAUNCH(KIND_BVH_SPHERES, 16) : RT_LAUNCH(KIND_BVH_SPHERES, 32);
-    return s.bvh_depth <= 16 ? RT_LAUNCH(KIND_BVH_TRIANGLES, 16) : RT_LAUNCH(KIND_BVH_TRIANGLES, 32);
-#undef RT_LAUNCH
+    const bool spheres = which == RT_K_BVH_SPHERES;
+    const bool lds = fits_lds(s, spheres) && !p.force_global_scene;
+#define RT_BVH(KIND)                                                                                       \
+    if (lds) return histogram ? launch_bvh<KIND, 16, true, true, 512>(RT_ARGS)                             \
+                              : launch_bvh<KIND, 16, false, true, 512>(RT_ARGS);                           \
+    if (s.bvh_depth <= 16) return histogram ? launch_bvh<KIND, 16, true, false, 256>(RT_ARGS)              \
+                                            : launch_bvh<KIND, 16, false, false, 256>(RT_ARGS);            \
+    return histogram ? launch_bvh<KIND, 32, true, false, 256>(RT_ARGS)                                     \
+                     : launch_bvh<KIND, 32, false, false, 256>(RT_ARGS);
+    if (spheres) { RT_BVH(KIND_BVH_SPHERES) }
+    RT_BVH(KIND_BVH_TRIANGLES)
+#undef RT_BVH
+#undef RT_ARGS
 }
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,

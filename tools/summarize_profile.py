@@ -1,0 +1,43 @@
+"""Summarise gpurun_out/<tag>/ (tools/profile_bench.sh) into profiles/<name>_{kernel_stats.csv,bench.json,pmc.json}."""
+import collections, csv, glob, json, os, shutil, sys
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % name)
+ks = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], "profiles/%s_kernel_stats.csv" % name)
+bench = json.load(open(os.path.join(src, "bench.json")))
+agg = collections.defaultdict(float)
+info = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if "rt_trace_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            info = dict(kernel=r["Kernel_Name"][:90], VGPR_Count=r["VGPR_Count"], SGPR_Count=r["SGPR_Count"],
+                        LDS_Block_Size=r["LDS_Block_Size"], Grid_Size=r["Grid_Size"], Workgroup_Size=r["Workgroup_Size"])
+rays = bench["roofline"]["rays_per_launch"]
+d = {}
+if "SQ_INSTS_VALU" in agg:
+    d["valu_wave_insts_per_64_rays"] = agg["SQ_INSTS_VALU"] * 64 / rays
+    d["valu_lane_utilisation"] = agg["SQ_THREAD_CYCLES_VALU"] / (agg["SQ_INSTS_VALU"] * 64)
+    d["salu_per_valu"] = agg["SQ_INSTS_SALU"] / agg["SQ_INSTS_VALU"]
+if "FETCH_SIZE" in agg:
+    # MI355X_MICROARCH.md: FETCH_SIZE (KB) reports half the bytes of wide coalesced reads on gfx950; this kernel's
+    # HBM reads are the 12-byte-per-lane accum read-modify-write, so the factor is uncalibrated: both given.
+    d["hbm_read_bytes_counter"] = agg["FETCH_SIZE"] * 1024
+    d["hbm_read_bytes_x2_correction"] = agg["FETCH_SIZE"] * 2048
+if "WRITE_SIZE" in agg:
+    d["hbm_write_bytes"] = agg["WRITE_SIZE"] * 1024
+if "TCC_HIT_sum" in agg:
+    d["l2_hit_rate"] = agg["TCC_HIT_sum"] / max(1.0, agg["TCC_HIT_sum"] + agg["TCC_MISS_sum"])
+if "SQ_LDS_BANK_CONFLICT" in agg:
+    d["lds_conflict_fraction"] = agg["SQ_LDS_BANK_CONFLICT"] / max(1.0, agg["SQ_LDS_IDX_ACTIVE"])
+if "SQ_WAIT_INST_ANY" in agg:
+    d["wait_any_over_wave_cycles"] = agg["SQ_WAIT_ANY"] / max(1.0, agg.get("SQ_WAVE_CYCLES", 0) or 1)
+if "GRBM_GUI_ACTIVE" in agg:
+    d["effective_clock_ghz"] = agg["GRBM_GUI_ACTIVE"] / 8 / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9
+out = {"workload": bench["config"]["workload"], "dispatch": info, "counters_one_launch": dict(agg), "derived": d,
+       "bench": {k: bench[k] for k in ("value", "ms_per_step")}, "roofline": bench["roofline"]}
+json.dump(out, open("profiles/%s_pmc.json" % name, "w"), indent=1)
+print(json.dumps(d, indent=1))

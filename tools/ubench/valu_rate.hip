@@ -41,6 +41,21 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s)
             asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %0, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %2, vcc\n"
                          "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %4, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %6, vcc\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "vcc");
+        } else if (MODE == 8) { // 4 v_mad_u64_u32 (64-bit product + 64-bit add)
+            unsigned long long r0, r1, r2, r3;
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %8, 0\n v_mad_u64_u32 %1, vcc, %5, %8, 0\n v_mad_u64_u32 %2, vcc, %6, %8, 0\n v_mad_u64_u32 %3, vcc, %7, %8, 0\n"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(s) : "vcc");
+            a0 = (float)(unsigned)(r0 >> 32 ^ r0); a1 = (float)(unsigned)(r1 >> 32 ^ r1); a2 = (float)(unsigned)(r2 >> 32 ^ r2); a3 = (float)(unsigned)(r3 >> 32 ^ r3);
+        } else if (MODE == 9) { // 8 v_mul_hi_u32
+            asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
+                         "v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
+        } else if (MODE == 10) { // 8 v_fma_f64 (4 independent, 2 each)
+            double d0 = a0, d1 = a1, d2 = a2, d3 = a3, ds = s;
+            asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
+                         "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(ds));
+            a0 = (float)d0; a1 = (float)d1; a2 = (float)d2; a3 = (float)d3;
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -68,7 +83,7 @@ void run(const char *name, int wavesPerSimd, int instrPerIter, int laneOpsPerIte
 int main()
 {
     float *d; hipMalloc(&d, 256 * 8 * 256 * 4);
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4, 8}) {
         run<0>("v_mul_f32", w, 8, 8, d);
         run<1>("v_fma_f32", w, 8, 8, d);
         run<2>("v_pk_mul_f32", w, 4, 8, d);
@@ -77,6 +92,9 @@ int main()
         run<5>("v_sqrt_f32", w, 8, 8, d);
         run<6>("v_mul_lo_u32", w, 8, 8, d);
         run<7>("v_cmp+v_cndmask", w, 8, 8, d);
+        run<8>("v_mad_u64_u32 (+8 cvt/xor)", w, 4, 4, d);
+        run<9>("v_mul_hi_u32", w, 8, 8, d);
+        run<10>("v_fma_f64 (+cvts)", w, 8, 8, d);
     }
     return 0;
 }
