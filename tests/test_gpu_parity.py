@@ -132,6 +132,15 @@ def test_c2_two_sphere_reduced(gpu_ctx, flavour):
     _compare(res, oa, o8, orc, cnt)
 
 
+def test_lds_and_global_scene_variants_agree(gpu_ctx, monkeypatch):
+    """The book scene runs from LDS by default; RT_HIP_GLOBAL_SCENE forces the global-memory variant."""
+    a, _ = _both(gpu_ctx, "book", 160, 90, 6, flavour="bvh")
+    monkeypatch.setenv("RT_HIP_GLOBAL_SCENE", "1")
+    b, _ = _both(gpu_ctx, "book", 160, 90, 6, flavour="bvh")
+    assert np.array_equal(a.raycount, b.raycount)
+    assert np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32))
+
+
 def test_kernel_flavours_are_bit_identical(gpu_ctx):
     """The BVH only culls; the exact tests and the shading are the brute-force kernel's, so the two
     flavours must produce the same bits."""
@@ -222,6 +231,23 @@ def test_full_size_1080p_sampled_pixels(gpu_ctx, name, spp):
     assert np.array_equal(q, res.rgb8)                                          # tonemap (raytracer.zig:527)
     print("%s 1080p/%dspp: %d rays, kernel %.1f ms = %.0f Mrays/s, sampled max err %.3g"
           % (name, spp, res.rays, res.kernel_ms, res.rays / res.kernel_ms / 1e3, err))
+
+
+def test_c5_resolution_3840x2160_sampled_pixels(gpu_ctx):
+    """configs[4] geometry (4K, 8.3 M pixels; its 1024 spp are split over GPUs by bench.py/distributed.py):
+    one rank's share at reduced spp -- global sample indices [512, 516) of 1024 -- checked on random pixels."""
+    nx, ny = 3840, 2160
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    kw = dict(spp_begin=512, spp_end=516, spp_total=1024)
+    res = gpu_ctx.render(cam, R.make_config(nx, ny, 1024, **kw), want_raycount=True)
+    rng = np.random.default_rng(21)
+    pix = np.unique(np.concatenate([rng.integers(0, nx * ny, 3000), [0, nx * ny - 1]])).astype(np.uint32)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, _, orc, _ = O.render_counter(w, ocam, O.make_config(nx, ny, 1024, **kw), pixels=pix)
+    assert np.array_equal(res.raycount[pix], orc)
+    assert float(np.abs(res.accum[pix] - oa).max()) <= TOL_ACCUM
+    assert res.primary_rays == nx * ny * 4
 
 
 # ---- sharding properties (SURVEY 8(e)) -----------------------------------------------------------------

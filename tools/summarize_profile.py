@@ -12,7 +12,7 @@ agg = collections.defaultdict(float)
 info = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        if "rt_trace_kernel" in r["Kernel_Name"]:
+        if "rt_trace_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             info = dict(kernel=r["Kernel_Name"][:90], VGPR_Count=r["VGPR_Count"], SGPR_Count=r["SGPR_Count"],
                         LDS_Block_Size=r["LDS_Block_Size"], Grid_Size=r["Grid_Size"], Workgroup_Size=r["Workgroup_Size"])
