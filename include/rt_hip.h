@@ -71,9 +71,12 @@ typedef struct {
     uint64_t seed;                   /* counter-RNG key (the reference seeds sfc64 with i*123, :600) */
     uint32_t tile_x0, tile_y0, tile_x1, tile_y1;  /* output rect [x0,x1) x [y0,y1); all 0 = whole image */
     uint32_t row_offset_q3;          /* 1: j = ny - jr as raytracer.zig:523; 0: j = ny-1-jr */
-    uint32_t spp_chunk;              /* 0: one running sum per pixel (bit-matches the oracle's order);
-                                        >0: samples summed in chunks of this size (more parallel work items) */
+    uint32_t spp_chunk;              /* 0: one running sum per pixel, samples added in order as trace does
+                                        (raytracer.zig:535-541); C > 0: global samples [k*C,(k+1)*C) are summed per
+                                        chunk and the chunk sums added in order (more, smaller work items: a shorter
+                                        tail); RT_SPP_CHUNK_AUTO: the library picks C */
 } rt_config;
+#define RT_SPP_CHUNK_AUTO 0xFFFFFFFFu
 
 typedef struct {
     uint64_t rays;                   /* world.hit evaluations (primary + scattered) */

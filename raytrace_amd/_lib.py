@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
 RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2
+RT_SPP_CHUNK_AUTO = 0xFFFFFFFF
 RT_FLAG_DEPTH_HISTOGRAM, RT_FLAG_FORCE_BRUTE_FORCE, RT_FLAG_FORCE_BVH = 1, 2, 4
 
 f32p = C.POINTER(C.c_float)

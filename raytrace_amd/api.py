@@ -315,4 +315,5 @@ def render_and_write(fname, num_samples, world, shape, cam, device=0, seed=1, ma
     ny, nx = shape
     with Context(device) as ctx:
         ctx.upload_scene(world)
-        return ctx.render_and_write(fname, cam, make_config(nx, ny, num_samples, max_depth=max_depth, seed=seed))
+        return ctx.render_and_write(fname, cam, make_config(nx, ny, num_samples, max_depth=max_depth, seed=seed,
+                                                            spp_chunk=_lib.RT_SPP_CHUNK_AUTO))

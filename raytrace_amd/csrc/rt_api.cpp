@@ -33,6 +33,7 @@ struct rt_ctx {
     uint32_t    *d_queue = nullptr;            // work-queue head
     unsigned long long *d_stats = nullptr;     // RT_STATS_WORDS
     float       *d_accum = nullptr;  size_t accum_cap = 0;     // floats
+    float       *d_partial = nullptr; size_t partial_cap = 0;  // chunked mode: n_chunks planes of P*3 floats
     uint32_t    *d_raycount = nullptr; size_t raycount_cap = 0;
     float       *d_mean = nullptr;   size_t mean_cap = 0;
     uint8_t     *d_rgb8 = nullptr;   size_t rgb8_cap = 0;
@@ -66,12 +67,15 @@ int check_config(const rt_config *cfg)
     if (cfg->nx >= (1u << 24) || cfg->ny >= (1u << 24)) return RT_E_ARG;     // f32(i), f32(j) exact
     if (cfg->spp_end < cfg->spp_begin || cfg->spp_total == 0) return RT_E_ARG;
     if (cfg->max_depth > 1000000u) return RT_E_ARG;
+    if (cfg->spp_chunk != 0 && cfg->spp_chunk != RT_SPP_CHUNK_AUTO) {
+        const uint64_t nc = ((uint64_t)cfg->spp_end + cfg->spp_chunk - 1) / cfg->spp_chunk - cfg->spp_begin / cfg->spp_chunk;
+        if (nc > 4096 || nc * ((uint64_t)cfg->nx * cfg->ny + 4096) * 64 > 0xFFFFFFFFull) return RT_E_ARG;
+    }
     const bool whole = !cfg->tile_x0 && !cfg->tile_y0 && !cfg->tile_x1 && !cfg->tile_y1;
     if (!whole) {
         if (cfg->tile_x0 >= cfg->tile_x1 || cfg->tile_y0 >= cfg->tile_y1) return RT_E_ARG;
         if (cfg->tile_x1 > cfg->nx || cfg->tile_y1 > cfg->ny) return RT_E_ARG;
     }
-    if (cfg->spp_chunk != 0) return RT_E_ARG;   // chunked summation is not built yet
     return RT_OK;
 }
 
@@ -92,10 +96,36 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.x1 = whole ? cfg->nx : cfg->tile_x1; p.y1 = whole ? cfg->ny : cfg->tile_y1;
     p.tiles_x = (p.x1 - p.x0 + 7u) / 8u;
     const uint32_t tiles_y = (p.y1 - p.y0 + 7u) / 8u;
-    p.n_items = p.tiles_x * tiles_y * 64u;
+    // sample chunking: chunk k = global samples [k*C, (k+1)*C); one work item per (pixel, chunk)
+    uint32_t chunk = cfg->spp_chunk;
+    const uint32_t n_spp = cfg->spp_end - cfg->spp_begin;
+    const uint64_t pixel_items = (uint64_t)p.tiles_x * tiles_y * 64u;
+    if (chunk == RT_SPP_CHUNK_AUTO) {
+        // enough items to keep the tail short (>= ~16 per lane of a full chip), chunks of at least 4 samples
+        const uint64_t want_items = 64ull * 256 * 2048;
+        chunk = 0;
+        if (n_spp >= 8 && pixel_items < want_items) {
+            uint64_t nc = (want_items + pixel_items - 1) / pixel_items;
+            if (nc > n_spp / 4) nc = n_spp / 4;
+            if (nc > 64) nc = 64;
+            if (nc > 1) chunk = (uint32_t)((n_spp + nc - 1) / nc);
+        }
+    }
+    p.spp_chunk = 0; p.chunk0 = 0; p.n_chunks = 1;
+    if (chunk != 0 && n_spp > 0) {
+        const uint32_t c0 = cfg->spp_begin / chunk, c1 = (cfg->spp_end + chunk - 1) / chunk;
+        if (c1 - c0 > 1) { p.spp_chunk = chunk; p.chunk0 = c0; p.n_chunks = c1 - c0; }
+    }
+    p.plane_stride = (size_t)cfg->nx * cfg->ny * 3;
+    p.queue_batch = p.n_chunks > 1 ? 128u : 64u;    // coarse items (whole pixels): reserve less, the tail is long enough
+    if (const char *e = std::getenv("RT_HIP_QUEUE_BATCH")) {         // tuning knob
+        const int v = std::atoi(e);
+        if (v >= 64 && v <= 4096) p.queue_batch = (uint32_t)v;
+    }
+    p.n_items = (uint32_t)(pixel_items * p.n_chunks);
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
-    p.keep_traversing = 1;
+    p.keep_traversing = 8;
     p.force_global_scene = std::getenv("RT_HIP_GLOBAL_SCENE") ? 1u : 0u;
     if (const char *e = std::getenv("RT_HIP_KEEP_TRAVERSING")) {    // tuning knob (1..64)
         const int v = std::atoi(e);
@@ -129,10 +159,20 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;
     s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth;
     ctx->last_kernel = pick_kernel(ctx);
+    if (p.n_chunks > 1) {        // scratch planes for the per-chunk partial sums (every cell is written)
+        const int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, p.plane_stride * p.n_chunks);
+        if (rc != RT_OK) return rc;
+        if (p.x0 != 0 || p.y0 != 0 || p.x1 != cfg->nx || p.y1 != cfg->ny)   // tiles leave cells untouched
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_partial, 0, p.plane_stride * p.n_chunks * sizeof(float), stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (cfg->spp_end > cfg->spp_begin)
-        HIP_TRY(ctx, rt_launch_trace(ctx->last_kernel, p, s, d_accum_sum, d_raycount, ctx->d_queue, ctx->d_stats, hist,
-                                     ctx->num_cus, stream));
+    if (cfg->spp_end > cfg->spp_begin) {
+        HIP_TRY(ctx, rt_launch_trace(ctx->last_kernel, p, s, d_accum_sum, ctx->d_partial, d_raycount, ctx->d_queue,
+                                     ctx->d_stats, hist, ctx->num_cus, stream));
+        if (p.n_chunks > 1)
+            HIP_TRY(ctx, rt_launch_reduce_chunks(d_accum_sum, ctx->d_partial, cfg->nx * cfg->ny, p.n_chunks,
+                                                 p.plane_stride, stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     return RT_OK;
 }
@@ -218,7 +258,7 @@ void rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
     (void)hipFree(ctx->d_bvh);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
-    (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
+    (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_partial); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

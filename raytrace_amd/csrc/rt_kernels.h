@@ -16,6 +16,9 @@ struct TraceParams {
     uint32_t n_items;                       // work items = tiles * 64 (one per pixel slot)
     uint32_t q3;                            // 1: j = ny - jr (raytracer.zig:523)
     uint32_t n_prim;
+    uint32_t spp_chunk, chunk0, n_chunks;   // n_chunks > 1: samples summed per chunk into partial planes
+    uint32_t queue_batch;                   // work items a wave reserves per global atomic (>= 64)
+    size_t   plane_stride;                  // floats between partial planes
     uint32_t force_global_scene;            // BVH kernels: 1 = never stage the scene in LDS (test/tuning knob)
     uint32_t keep_traversing;               // BVH kernels: leave the traversal loop when fewer lanes than this traverse
 };
@@ -46,9 +49,12 @@ enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANG
 enum { RT_STATS_WORDS = 28 };
 
 hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const DeviceScene &s, float *accum_sum,
-                           uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
+                           float *partial, uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
                            bool histogram, int num_cus, hipStream_t stream);
 const char *rt_trace_kernel_name(TraceKernel which);
+
+hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,
+                                   size_t plane_stride, hipStream_t stream);
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,
                              float *mean, uint8_t *rgb8, hipStream_t stream);

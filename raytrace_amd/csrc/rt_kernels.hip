@@ -47,6 +47,8 @@ struct Lane {
     uint32_t pix;         // output index jr*nx+i
     uint32_t i, j;        // pixel column and the reference's j (raytracer.zig:523)
     uint32_t sample;      // global sample index
+    uint32_t send;        // end of this lane's sample range (the whole range, or one chunk of it)
+    uint32_t part;        // chunk slot (index of the partial-sum plane) when samples are chunked
     uint32_t depth;
     uint32_t nrays;       // world.hit evaluations of this pixel
 };
@@ -180,8 +182,10 @@ enum { KIND_BRUTE_SPHERES = 0, KIND_BVH_SPHERES = 1, KIND_BVH_TRIANGLES = 2 };
 
 struct Outputs {
     float              *accum;
+    float              *partial;   // chunked mode: [n_chunks][P*3] partial sums, each cell written by one lane
     uint32_t           *raycount;
     uint32_t           *queue;
+    uint32_t           *wave_queue;   // LDS: this wave's reserved item range {next, end}
     unsigned long long  my_rays, my_primary;
 };
 
@@ -191,25 +195,52 @@ struct Outputs {
 // and trace's, :536-541.  Returns true when a camera ray is to be generated for (L.pix, L.sample).
 __device__ __forceinline__ bool advance(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane)
 {
-    if (L.sample >= P.spp_end) {
-        if (L.pix != NOPIX) {                         // pixel finished: this lane is its only writer
-            float *dst = O.accum + 3ull * L.pix;
-            dst[0] += L.col.x; dst[1] += L.col.y; dst[2] += L.col.z;
-            if (O.raycount) O.raycount[L.pix] += L.nrays;
+    if (L.sample >= L.send) {
+        if (L.pix != NOPIX) {                         // (pixel, sample range) finished: this lane is its only writer
+            if (P.n_chunks > 1u) {
+                float *dst = O.partial + (size_t)L.part * P.plane_stride + 3ull * L.pix;
+                dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
+                if (O.raycount) atomicAdd(&O.raycount[L.pix], L.nrays);
+            } else {
+                float *dst = O.accum + 3ull * L.pix;
+                dst[0] += L.col.x; dst[1] += L.col.y; dst[2] += L.col.z;
+                if (O.raycount) O.raycount[L.pix] += L.nrays;
+            }
             O.my_rays += L.nrays;
             L.pix = NOPIX;
         }
+        // Dequeue.  Every wave owns a reserved range of work items [next, end) (kept in LDS, touched only by the
+        // wave's leader lane); the lanes that need an item take consecutive ones from it (ballot + popcount
+        // rank), and only when the range runs dry does the leader reserve the next P.queue_batch items with ONE
+        // atomic on the global head.  (One atomic per item saturates a single counter at this kernel's rate.)
         const unsigned long long m = __ballot(1);
+        const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(O.queue, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);  // leader = first active lane
-        const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint32_t q_next = 0, q_avail = 0, q_new = 0;
+        if (lane == leader) {
+            uint32_t *wq = O.wave_queue;
+            q_next = wq[0];
+            q_avail = wq[1] - q_next;
+            if (cnt > q_avail) {
+                q_new = atomicAdd(O.queue, P.queue_batch);
+                wq[0] = q_new + (cnt - q_avail);
+                wq[1] = q_new + P.queue_batch;
+            } else {
+                wq[0] = q_next + cnt;
+            }
+        }
+        q_next = __builtin_amdgcn_readfirstlane(q_next);   // leader = first active lane
+        q_avail = __builtin_amdgcn_readfirstlane(q_avail);
+        q_new = __builtin_amdgcn_readfirstlane(q_new);
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t item = rank < q_avail ? q_next + rank : q_new + (rank - q_avail);
         if (item >= P.n_items) {
             alive = false;
         } else {
-            // item -> pixel: 8x8 tiles, row-major inside a tile, so a wave starts on one coherent tile
-            const uint32_t tile = item >> 6, within = item & 63u;
+            // item -> (tile, chunk, pixel): 8x8 tiles, row-major inside a tile, so a wave starts on one
+            // coherent tile; the chunks of a tile are consecutive items
+            const uint32_t slot = item >> 6, within = item & 63u;
+            const uint32_t tile = slot / P.n_chunks, part = slot - tile * P.n_chunks;
             const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
             const uint32_t i = P.x0 + tx * 8u + (within & 7u);
             const uint32_t jr = P.y0 + ty * 8u + (within >> 3);
@@ -217,13 +248,22 @@ __device__ __forceinline__ bool advance(const TraceParams &P, Lane &L, bool &ali
                 L.pix = jr * P.nx + i;                // raytracer.zig:521-528 output index
                 L.i = i;
                 L.j = P.q3 ? (P.ny - jr) : (P.ny - 1u - jr);   // raytracer.zig:523
-                L.sample = P.spp_begin;
+                L.part = part;
+                if (P.n_chunks > 1u) {                // chunk k covers global samples [k*C, (k+1)*C)
+                    const uint32_t k = P.chunk0 + part;
+                    const uint32_t lo = k * P.spp_chunk, hi = lo + P.spp_chunk;
+                    L.sample = lo > P.spp_begin ? lo : P.spp_begin;
+                    L.send = hi < P.spp_end ? hi : P.spp_end;
+                } else {
+                    L.sample = P.spp_begin;
+                    L.send = P.spp_end;
+                }
                 L.col = mk(0, 0, 0);
                 L.nrays = 0;
             }
         }
     }
-    return L.pix != NOPIX && L.sample < P.spp_end;
+    return L.pix != NOPIX && L.sample < L.send;
 }
 
 // Everything between two world.hit calls of a lane: the rest of color() after the hit test
@@ -288,20 +328,20 @@ __device__ __forceinline__ void finish(const Outputs &O, unsigned long long *sta
 template <bool HIST>
 __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     const TraceParams P, const float4 *__restrict__ geom, const float4 *__restrict__ aux,
-    const float4 *__restrict__ albedo, float *__restrict__ accum, uint32_t *__restrict__ raycount,
-    uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
+    const float4 *__restrict__ albedo, float *__restrict__ accum, float *__restrict__ partial,
+    uint32_t *__restrict__ raycount, uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t s_hist[20];
-    if (HIST) {
-        if (threadIdx.x < 20) s_hist[threadIdx.x] = 0;
-        __syncthreads();
-    }
+    __shared__ uint32_t s_wq[2 * (BLOCK / 64)];
+    if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * (BLOCK / 64)) s_wq[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     Lane L;
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
-    L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = P.spp_end; L.depth = 0; L.nrays = 0;
+    L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = 0; L.send = 0; L.part = 0; L.depth = 0; L.nrays = 0;
     bool alive = true, has_ray = false;
-    Outputs O{ accum, raycount, queue, 0ull, 0ull };
+    Outputs O{ accum, partial, raycount, queue, s_wq + 2 * (threadIdx.x >> 6), 0ull, 0ull };
 
     float a = 1.0f, best_t = T_MAX;
     uint32_t best = NOHIT;
@@ -356,7 +396,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     const TraceParams P,
     const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
     const float4 *__restrict__ albedo, const float4 *__restrict__ bvh, const uint32_t n_nodes,
-    float *__restrict__ accum, uint32_t *__restrict__ raycount,
+    float *__restrict__ accum, float *__restrict__ partial, uint32_t *__restrict__ raycount,
     uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
 {
     typedef typename std::conditional<LDSN, uint16_t, uint32_t>::type idx_t;
@@ -366,7 +406,9 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     __shared__ idx_t s_cand[CAND * BLOCK];
     extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
     const float4 *s_geom = s_scene + (LDSN ? n_nodes * LDS_NODE_STRIDE : 0u);
+    __shared__ uint32_t s_wq[2 * (NT / 64)];
     if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
         for (uint32_t k = threadIdx.x; k < n_nodes * 4u; k += NT)
             s_scene[(k >> 2) * LDS_NODE_STRIDE + (k & 3u)] = bvh[k];
@@ -374,15 +416,15 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
                 s_scene[n_nodes * LDS_NODE_STRIDE + k] = geom[k];
     }
-    if (HIST || LDSN) __syncthreads();
+    __syncthreads();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
 
     Lane L;
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
-    L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = P.spp_end; L.depth = 0; L.nrays = 0;
+    L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = 0; L.send = 0; L.part = 0; L.depth = 0; L.nrays = 0;
     bool alive = true, has_ray = false;
-    Outputs O{ accum, raycount, queue, 0ull, 0ull };
+    Outputs O{ accum, partial, raycount, queue, s_wq + 2 * (threadIdx.x >> 6), 0ull, 0ull };
 
     // traversal state of the lane's current ray
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
@@ -494,6 +536,17 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     }
 }
 
+// chunked mode: accum += (((p[0] + p[1]) + p[2]) + ...), the chunk partial sums added in sample order
+__global__ __launch_bounds__(256) void rt_reduce_chunks_kernel(float *accum, const float *partial, uint32_t n_values,
+                                                               uint32_t n_chunks, size_t plane_stride)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_values) return;
+    float acc = 0.0f;
+    for (uint32_t c = 0; c < n_chunks; ++c) acc += partial[c * plane_stride + k];
+    accum[k] += acc;
+}
+
 // mean = sum / spp_total (raytracer.zig:542), sqrt gamma (:545-549), 255.99 truncation (:527)
 __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float *accum_sum, uint32_t n_values, float spp_total,
                                                          float *mean, uint8_t *rgb8)
@@ -546,25 +599,25 @@ static bool fits_lds(const DeviceScene &s, bool spheres)
 }
 
 template <int KIND, int STACK, bool HIST, bool LDSN, int NT>
-hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, uint32_t *raycount,
+hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, float *partial, uint32_t *raycount,
                       uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
 {
     auto kern = rt_trace_bvh_kernel<KIND, STACK, HIST, LDSN, NT>;
     const size_t dyn = LDSN ? lds_scene_bytes(s, KIND == KIND_BVH_SPHERES) : 0;
     const long long grid = grid_for((const void *)kern, p, num_cus, NT, dyn);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), dyn, stream,
-                       p, s.geom, s.tri, s.aux, s.albedo, s.bvh, s.n_nodes, accum_sum, raycount, queue, stats);
+                       p, s.geom, s.tri, s.aux, s.albedo, s.bvh, s.n_nodes, accum_sum, partial, raycount, queue, stats);
     return hipGetLastError();
 }
 
 template <bool HIST>
-hipError_t launch_brute(const TraceParams &p, const DeviceScene &s, float *accum_sum, uint32_t *raycount,
+hipError_t launch_brute(const TraceParams &p, const DeviceScene &s, float *accum_sum, float *partial, uint32_t *raycount,
                         uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
 {
     auto kern = rt_trace_brute_kernel<HIST>;
     const long long grid = grid_for((const void *)kern, p, num_cus, BLOCK, 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), 0, stream,
-                       p, s.geom, s.aux, s.albedo, accum_sum, raycount, queue, stats);
+                       p, s.geom, s.aux, s.albedo, accum_sum, partial, raycount, queue, stats);
     return hipGetLastError();
 }
 
@@ -580,10 +633,10 @@ const char *rt_trace_kernel_name(TraceKernel which)
 }
 
 hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const DeviceScene &s, float *accum_sum,
-                           uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
+                           float *partial, uint32_t *raycount, uint32_t *queue, unsigned long long *stats,
                            bool histogram, int num_cus, hipStream_t stream)
 {
-#define RT_ARGS p, s, accum_sum, raycount, queue, stats, num_cus, stream
+#define RT_ARGS p, s, accum_sum, partial, raycount, queue, stats, num_cus, stream
     if (which == RT_K_BRUTE_SPHERES) return histogram ? launch_brute<true>(RT_ARGS) : launch_brute<false>(RT_ARGS);
     if (s.bvh_depth > 32 || !s.bvh) return hipErrorInvalidValue;
     const bool spheres = which == RT_K_BVH_SPHERES;
@@ -599,6 +652,16 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
     RT_BVH(KIND_BVH_TRIANGLES)
 #undef RT_BVH
 #undef RT_ARGS
+}
+
+hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,
+                                   size_t plane_stride, hipStream_t stream)
+{
+    const uint32_t n = n_pixels * 3u;
+    if (n == 0 || n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_reduce_chunks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream,
+                       accum_sum, partial, n, n_chunks, plane_stride);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,

@@ -49,7 +49,9 @@ class ShardedResult:
 class HipRangeRenderer:
     """The product renderer of one rank: rt_render_device on this rank's GPU."""
 
-    def __init__(self, ctx, cam, nx, ny, max_depth=16, seed=1, t_min=0.001):
+    def __init__(self, ctx, cam, nx, ny, max_depth=16, seed=1, t_min=0.001, spp_chunk=None):
+        from ._lib import RT_SPP_CHUNK_AUTO
+        self.spp_chunk = RT_SPP_CHUNK_AUTO if spp_chunk is None else spp_chunk
         self.ctx, self.cam = ctx, cam
         self.nx, self.ny, self.max_depth, self.seed, self.t_min = nx, ny, max_depth, seed, t_min
 
@@ -62,7 +64,7 @@ class HipRangeRenderer:
         import torch
         from .api import make_config
         cfg = make_config(self.nx, self.ny, spp_total, max_depth=self.max_depth, seed=self.seed, t_min=self.t_min,
-                          spp_begin=spp_begin, spp_end=spp_end, spp_total=spp_total)
+                          spp_begin=spp_begin, spp_end=spp_end, spp_total=spp_total, spp_chunk=self.spp_chunk)
         rays, _prim, ms, _ = self.ctx.render_device(self.cam, cfg, accum.data_ptr(), 0,
                                                     torch.cuda.current_stream().cuda_stream, want_stats=True)
         return rays, ms

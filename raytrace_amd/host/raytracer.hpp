@@ -207,7 +207,7 @@ inline int render_and_write(rt_ctx *ctx, const std::string &fname, uint16_t num_
     rt_config cfg{};
     cfg.nx = (uint32_t)shape.nx; cfg.ny = (uint32_t)shape.ny;
     cfg.spp_begin = 0; cfg.spp_end = num_samples; cfg.spp_total = num_samples;
-    cfg.max_depth = 16; cfg.t_min = 0.001f; cfg.seed = seed; cfg.row_offset_q3 = 1;
+    cfg.max_depth = 16; cfg.t_min = 0.001f; cfg.seed = seed; cfg.row_offset_q3 = 1; cfg.spp_chunk = RT_SPP_CHUNK_AUTO;
     const rt_camera c = cam.to_abi();
     if (filetype != img_io::ImgType::ppm) return rt_render(ctx, &c, &cfg, nullptr, nullptr, nullptr, stats);
     return rt_render_and_write(ctx, fname.c_str(), &c, &cfg, stats);

@@ -264,6 +264,28 @@ def test_spp_ranges_sum_to_the_whole(gpu_ctx):
     assert empty.rays == 0 and not empty.accum.any() and not empty.raycount.any()
 
 
+@pytest.mark.parametrize("chunk", [1, 3, 5, 16, R.RT_SPP_CHUNK_AUTO])
+def test_sample_chunks_match_the_oracle_chunk_mode(gpu_ctx, chunk):
+    """spp_chunk: samples summed per chunk of global sample indices, chunk sums added in order -- the oracle
+    has the same mode.  Ray counts are exact; also checks a range that starts inside a chunk."""
+    nx, ny = 100, 60
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    w = O.World(spheres=spheres_to_oracle(s))
+    for kw in (dict(), dict(spp_begin=4, spp_end=13, spp_total=13)):
+        spp = 13
+        res = gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=chunk, **kw), want_raycount=True)
+        ochunk = 0 if chunk == R.RT_SPP_CHUNK_AUTO else chunk
+        oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, spp_chunk=ochunk, **kw))
+        _compare(res, oa, o8, orc, cnt)
+    tile = gpu_ctx.render(cam, R.make_config(nx, ny, 12, spp_chunk=4, tile=(10, 5, 61, 44)), want_raycount=True)
+    full = gpu_ctx.render(cam, R.make_config(nx, ny, 12, spp_chunk=4), want_raycount=True)
+    m = np.zeros((ny, nx), bool); m[5:44, 10:61] = True
+    assert np.array_equal(tile.raycount.reshape(ny, nx)[m], full.raycount.reshape(ny, nx)[m])
+    assert not tile.raycount.reshape(ny, nx)[~m].any() and not tile.accum.reshape(ny, nx, 3)[~m].any()
+    assert np.array_equal(tile.accum.reshape(ny, nx, 3)[m].view(np.uint32), full.accum.reshape(ny, nx, 3)[m].view(np.uint32))
+
+
 def test_tiles_equal_the_subrectangle(gpu_ctx):
     nx, ny, spp = 100, 60, 4
     s, cam, _ = _scene("book", nx, ny)

@@ -9,8 +9,9 @@ ctx = R.Context(0)
 book = R.Random_Scene(11, 0)
 ctx.upload_scene(book)
 cam = R.book_camera(1920, 1080)
+chunk = int(os.environ.get("TUNE_CHUNK", "0"))
 for _ in range(3):
-    res = ctx.render(cam, R.make_config(1920, 1080, 100))
+    res = ctx.render(cam, R.make_config(1920, 1080, 100, spp_chunk=chunk))
 print("C3 %8.2f ms %8.0f Mrays/s" % (res.kernel_ms, res.rays / res.kernel_ms / 1e3), end="  ")
 if os.environ.get("TUNE_C4"):
     tris = R.Tessellate_Spheres(book, 0, 0)
