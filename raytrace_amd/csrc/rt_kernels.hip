@@ -80,44 +80,43 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
 {
     const f3 p = S.p, n = S.n;
     f3 dir;
-    if (S.kind == K_LAMBERTIAN) {
-        // random_in_unit_sphere, raytracer.zig:574-578; Lambertian.scatter, :438-445
+    f3 reflected = mk(0.0f, 0.0f, 0.0f);
+    if (S.kind != K_LAMBERTIAN) {                                  // reflect, :420-422 / :450-452
+        const float dn_u = dot(unit, n);
+        reflected = unit - (2.0f * dn_u) * n;
+    }
+    if (S.kind != K_DIELECTRIC) {
+        // random_in_unit_sphere, raytracer.zig:574-578 -- once for the lambertian and the metal lanes together
         const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
         const f3 cn = cube / sqrtf(dot(cube, cube));
         const float cb = cbrt_f32(u32_to_unit_float(r[3]));
         const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
-        const f3 target = (p + n) + rius;
-        dir = target - p;
-    } else {
-        const float dn_u = dot(unit, n);
-        const f3 reflected = unit - (2.0f * dn_u) * n;             // reflect, :420-422 / :450-452
-        if (S.kind == K_METAL) {                                   // Metal.scatter, :423-433
-            const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
-            const f3 cn = cube / sqrtf(dot(cube, cube));
-            const float cb = cbrt_f32(u32_to_unit_float(r[3]));
-            const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
+        if (S.kind == K_LAMBERTIAN) {                              // Lambertian.scatter, :438-445
+            const f3 target = (p + n) + rius;
+            dir = target - p;
+        } else {                                                   // Metal.scatter, :423-433
             dir = reflected + S.param * rius;
             if (!(dot(dir, n) > 0)) return false;                  // absorbed: the path returns black
-        } else {                                                   // Dielectric.scatter, :469-499
-            const float param = S.param;
-            const float ddn = dot(L.d, n);
-            f3 on; float ni_over_nt, cosine;
-            if (ddn > 0) { on = -n; ni_over_nt = param; cosine = (param * ddn) / len_d; }
-            else { on = n; ni_over_nt = 1.0f / param; cosine = (-ddn) / len_d; }
-            const float dt = dot(unit, on);                        // refract, :453-463
-            const float disc = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
-            float reflect_prob = 1.0f;
-            f3 refracted = mk(0.0f, 0.0f, 0.0f);
-            if (disc > 0) {
-                const float sq = sqrtf(disc);
-                const f3 w = unit - dt * on;                       // uv - n*splat(dt)
-                refracted = mk(ni_over_nt * w.x - on.x * sq, ni_over_nt * w.y - on.y * sq, ni_over_nt * w.z - on.z * sq);
-                float r0 = (1.0f - param) / (1.0f + param);        // schlick, :464-468
-                r0 = r0 * r0;
-                reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
-            }
-            dir = (u32_to_unit_float(r[0]) < reflect_prob) ? reflected : refracted;   // :492-496
         }
+    } else {                                                       // Dielectric.scatter, :469-499
+        const float param = S.param;
+        const float ddn = dot(L.d, n);
+        f3 on; float ni_over_nt, cosine;
+        if (ddn > 0) { on = -n; ni_over_nt = param; cosine = (param * ddn) / len_d; }
+        else { on = n; ni_over_nt = 1.0f / param; cosine = (-ddn) / len_d; }
+        const float dt = dot(unit, on);                            // refract, :453-463
+        const float disc = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
+        float reflect_prob = 1.0f;
+        f3 refracted = mk(0.0f, 0.0f, 0.0f);
+        if (disc > 0) {
+            const float sq = sqrtf(disc);
+            const f3 w = unit - dt * on;                           // uv - n*splat(dt)
+            refracted = mk(ni_over_nt * w.x - on.x * sq, ni_over_nt * w.y - on.y * sq, ni_over_nt * w.z - on.z * sq);
+            float r0 = (1.0f - param) / (1.0f + param);            // schlick, :464-468
+            r0 = r0 * r0;
+            reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
+        }
+        dir = (u32_to_unit_float(r[0]) < reflect_prob) ? reflected : refracted;   // :492-496
     }
     L.thr = L.thr * S.albedo;
     L.o = p; L.d = dir;

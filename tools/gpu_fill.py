@@ -7,7 +7,7 @@ book = R.Random_Scene(11, 0)
 ctx.upload_scene(book)
 ctx.set_flags(R.RT_FLAG_DEPTH_HISTOGRAM)
 cam = R.book_camera(1920, 1080)
-res = ctx.render(cam, R.make_config(1920, 1080, 20))
+res = ctx.render(cam, R.make_config(1920, 1080, 100, spp_chunk=R.RT_SPP_CHUNK_AUTO))
 f = ctx.wave_fill()
 rays = res.rays
 print("keep=%s rays %d kernel %.2f ms" % (os.environ.get("RT_HIP_KEEP_TRAVERSING"), rays, res.kernel_ms))
