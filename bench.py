@@ -133,6 +133,16 @@ def main():
             op = json.load(f)
         fpr = op["flops_per_ray"]
         k_ms = float(np.mean(kernel_ms))
+        # HBM bytes per launch of the trace kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE,
+        # WRITE_SIZE; tools/profile_bench.sh), committed under profiles/: counters cannot be read in-process.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "latest_%s_pmc.json" % args.workload)
+        if world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                d = json.load(f).get("derived", {})
+            if "hbm_write_bytes" in d and "hbm_read_bytes_counter" in d:
+                traffic = d["hbm_read_bytes_counter"] + d["hbm_write_bytes"]
+                traffic_src = "profiles/latest_%s_pmc.json (FETCH_SIZE*1KiB uncorrected + WRITE_SIZE*1KiB)" % args.workload
         achieved = rays_per_step[0] * fpr / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/sec (all bounces) book scene 1080p 100spp; %FP32 VALU roofline",
@@ -143,7 +153,7 @@ def main():
                        "spp_per_gpu": spp, "spp_total": spp * world, "max_depth": depth, "seed": 1,
                        "rays_per_step": rays_all, "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
                          "kernel_mrays_per_s": rays_per_step[0] / (k_ms * 1e-3) / 1e6,

@@ -133,6 +133,13 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
 int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
                      float *d_accum_sum, uint32_t *d_raycount, void *stream, rt_stats *stats);
 
+/* The reference's own merge (quirk Q4), for A/B against a Zig render: n_images whole-image renders of
+ * cfg->spp_total samples each, image i keyed with seed i*123 (raytracer.zig:600; cfg->seed is ignored), each
+ * gamma'd and quantised to u8 (raytracer.zig:527), then the per-channel INTEGER mean of the u8 images
+ * (raytracer.zig:610-617).  n_images plays the role of getCpuCount().  rgb8 is a host buffer [ny*nx*3]. */
+int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_images,
+                              uint8_t *rgb8, rt_stats *stats);
+
 /* Device tonemap: mean = sum / spp_total; rgb8 = trunc(255.99*sqrt(mean)) (raytracer.zig:527,542-549).
  * d_mean and d_rgb8 may each be NULL; d_mean may alias d_accum_sum. */
 int rt_tonemap_device(rt_ctx *ctx, const float *d_accum_sum, uint32_t n_pixels, uint32_t spp_total,

@@ -266,6 +266,15 @@ class Context:
         rays, prim, ms, hist = _stats_tuple(st)
         return RenderResult(accum, rgb8, rc_arr, rays, prim, ms, hist)
 
+    def render_reference_style(self, cam, cfg, n_images):
+        """rt_render_reference_style: the reference's N-images u8 integer mean (raytracer.zig:594-617)."""
+        rgb8 = np.zeros((cfg.nx * cfg.ny, 3), np.uint8)
+        st = rt_stats()
+        rc = self._L.rt_render_reference_style(self._h, C.byref(cam.to_abi()), C.byref(cfg), n_images,
+                                               rgb8.ctypes.data, C.byref(st))
+        self._check(rc, "rt_render_reference_style")
+        return rgb8, _stats_tuple(st)
+
     def render_device(self, cam, cfg, d_accum_sum, d_raycount=0, stream=0, want_stats=True):
         """rt_render_device: adds into a device accumulation buffer (raw device pointers as ints)."""
         st = rt_stats()

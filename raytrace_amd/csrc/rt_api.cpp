@@ -126,6 +126,11 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
     p.keep_traversing = 8;
+    p.flush_lanes = 24;                              // 65 = only the "queue nearly full" rule
+    if (const char *e = std::getenv("RT_HIP_FLUSH_LANES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 65) p.flush_lanes = (uint32_t)v;
+    }
     p.force_global_scene = std::getenv("RT_HIP_GLOBAL_SCENE") ? 1u : 0u;
     if (const char *e = std::getenv("RT_HIP_KEEP_TRAVERSING")) {    // tuning knob (1..64)
         const int v = std::atoi(e);
@@ -420,6 +425,40 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *ac
     if (raycount) HIP_TRY(ctx, hipMemcpyAsync(raycount, ctx->d_raycount, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (stats) { if ((rc = read_stats(ctx, st, stats)) != RT_OK) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_images,
+                              uint8_t *rgb8, rt_stats *stats)
+{
+    if (!ctx || !cam || !rgb8 || n_images == 0 || n_images > 65536) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)cfg->nx * cfg->ny;
+    if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_rgb8, ctx->rgb8_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_raycount, ctx->raycount_cap, npix * 3)) != RT_OK) return rc;   // reused as the u32 sum
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_raycount, 0, npix * 3 * sizeof(uint32_t), st));
+    rt_stats total; std::memset(&total, 0, sizeof total);
+    for (uint32_t i = 0; i < n_images; ++i) {
+        rt_config c = *cfg;
+        c.seed = (uint64_t)i * 123u;                              // raytracer.zig:600
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, npix * 3 * sizeof(float), st));
+        if ((rc = enqueue_trace(ctx, cam, &c, ctx->d_accum, nullptr, st)) != RT_OK) return rc;
+        HIP_TRY(ctx, rt_launch_tonemap(ctx->d_accum, (uint32_t)npix, c.spp_total, nullptr, ctx->d_rgb8, st));   // :527
+        HIP_TRY(ctx, rt_launch_u8_sum(ctx->d_raycount, ctx->d_rgb8, (uint32_t)(npix * 3), st));              // :611-614
+        rt_stats one;
+        if ((rc = read_stats(ctx, st, &one)) != RT_OK) return rc;
+        total.rays += one.rays; total.primary_rays += one.primary_rays; total.kernel_ms += one.kernel_ms;
+        for (int k = 0; k < 20; ++k) total.rays_by_depth[k] += one.rays_by_depth[k];
+    }
+    HIP_TRY(ctx, rt_launch_u8_mean(ctx->d_raycount, n_images, ctx->d_rgb8, (uint32_t)(npix * 3), st));      // :616
+    HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->d_rgb8, npix * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (stats) *stats = total;
     return RT_OK;
 }
 

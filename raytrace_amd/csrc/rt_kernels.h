@@ -20,6 +20,7 @@ struct TraceParams {
     uint32_t queue_batch;                   // work items a wave reserves per global atomic (>= 64)
     size_t   plane_stride;                  // floats between partial planes
     uint32_t force_global_scene;            // BVH kernels: 1 = never stage the scene in LDS (test/tuning knob)
+    uint32_t flush_lanes;                   // BVH kernels: run the exact tests when this many lanes hold candidates
     uint32_t keep_traversing;               // BVH kernels: leave the traversal loop when fewer lanes than this traverse
 };
 
@@ -58,6 +59,9 @@ hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint3
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,
                              float *mean, uint8_t *rgb8, hipStream_t stream);
+
+hipError_t rt_launch_u8_sum(uint32_t *sum, const uint8_t *rgb8, uint32_t n, hipStream_t stream);
+hipError_t rt_launch_u8_mean(const uint32_t *sum, uint32_t n_images, uint8_t *rgb8, uint32_t n, hipStream_t stream);
 
 hipError_t rt_launch_selftest(uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
                               float *out_cbrt, const uint32_t *ctr0, uint32_t *philox_out, hipStream_t stream);

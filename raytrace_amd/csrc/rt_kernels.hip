@@ -524,7 +524,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 }
             }
             // a queue is nearly full somewhere: run the exact tests for the whole wave
-            if (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) flush();
+            // ... or enough lanes hold candidates that a batch is well filled (a hit found early tightens best_t
+            // and prunes the rest of that lane's traversal)
+            if (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull ||
+                (uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) flush();
             if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
         }
     }
@@ -560,6 +563,19 @@ __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float *accum_sum,
         iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
         rgb8[k] = (uint8_t)iv;
     }
+}
+
+// render_and_write's merge of the per-thread images (raytracer.zig:610-617): per-channel integer sum of the
+// gamma'd u8 images, then a truncating divide by the image count
+__global__ __launch_bounds__(256) void rt_u8_sum_kernel(uint32_t *sum, const uint8_t *rgb8, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) sum[k] += (uint32_t)rgb8[k];
+}
+__global__ __launch_bounds__(256) void rt_u8_mean_kernel(const uint32_t *sum, uint32_t n_images, uint8_t *rgb8, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) rgb8[k] = (uint8_t)(sum[k] / n_images);
 }
 
 __global__ void rt_selftest_kernel(uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
@@ -670,6 +686,19 @@ hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(rt_tonemap_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream,
                        accum_sum, n, (float)spp_total, mean, rgb8);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_u8_sum(uint32_t *sum, const uint8_t *rgb8, uint32_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_u8_sum_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, sum, rgb8, n);
+    return hipGetLastError();
+}
+hipError_t rt_launch_u8_mean(const uint32_t *sum, uint32_t n_images, uint8_t *rgb8, uint32_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_u8_mean_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, sum, n_images, rgb8, n);
     return hipGetLastError();
 }
 

@@ -415,6 +415,27 @@ def test_render_device_and_tonemap_device(gpu_ctx):
     assert psnr_u8(rgb.cpu().numpy().reshape(-1, 3), host.rgb8) >= MIN_PSNR
 
 
+def test_reference_style_u8_mean_of_images(gpu_ctx):
+    """render_and_write's merge (raytracer.zig:594-617, quirk Q4): N whole-image renders keyed i*123, each
+    quantised to u8, integer mean.  Checker: the oracle rendered once per seed + numpy integer mean."""
+    nx, ny, spp, n_images = 64, 36, 3, 5
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    img, (rays, prim, _ms, _) = gpu_ctx.render_reference_style(cam, R.make_config(nx, ny, spp, seed=99), n_images)
+    w = O.World(spheres=spheres_to_oracle(s))
+    acc = np.zeros((nx * ny, 3), np.uint32)
+    orays = 0
+    for i in range(n_images):
+        _, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, seed=i * 123))
+        acc += o8
+        orays += cnt["rays"]
+    ref = (acc // n_images).astype(np.uint8)
+    assert rays == orays and prim == nx * ny * spp * n_images
+    assert psnr_u8(img, ref) >= MIN_PSNR
+    lin = gpu_ctx.render(cam, R.make_config(nx, ny, spp * n_images, seed=0)).rgb8   # the linear-mean image differs (Q4)
+    assert img.shape == lin.shape
+
+
 def test_render_and_write_ppm(gpu_ctx, tmp_path):
     """render_and_write (raytracer.zig:580-633) -> the same P3 file the oracle writes for its image."""
     nx, ny, spp = 48, 27, 4

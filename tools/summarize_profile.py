@@ -40,4 +40,6 @@ if "GRBM_GUI_ACTIVE" in agg:
 out = {"workload": bench["config"]["workload"], "dispatch": info, "counters_one_launch": dict(agg), "derived": d,
        "bench": {k: bench[k] for k in ("value", "ms_per_step")}, "roofline": bench["roofline"]}
 json.dump(out, open("profiles/%s_pmc.json" % name, "w"), indent=1)
+if len(sys.argv) > 3:
+    shutil.copy("profiles/%s_pmc.json" % name, "profiles/latest_%s_pmc.json" % sys.argv[3])
 print(json.dumps(d, indent=1))
