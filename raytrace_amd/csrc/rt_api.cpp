@@ -329,7 +329,9 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             prims.push_back(rtbvh::triangle_prim(a, b, c));
         }
     }
-    const rtbvh::Tree tree = rtbvh::build(prims);
+    int depth_cap = 24;                                        // 24-entry stacks: 5 workgroups per CU instead of 3
+    if (const char *e = std::getenv("RT_HIP_BVH_DEPTH_CAP")) { const int v = std::atoi(e); if (v >= 8 && v <= 32) depth_cap = v; }
+    const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
     if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
     std::vector<float4> nodes(tree.nodes.size() * 4);
     if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));

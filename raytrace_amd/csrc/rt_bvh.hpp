@@ -34,7 +34,7 @@ struct Prim { Box box; float c[3]; };
 // reference, because an inverted box is NOT unhittable for a min/max slab test).
 struct Node { float w[16]; };
 constexpr uint32_t LEAF_BIT = 0x80000000u;
-constexpr int MAX_DEPTH = 32;
+constexpr int MAX_DEPTH = 32;          // hard limit of the traversal stacks the kernels are built with
 
 struct Tree {
     std::vector<Node> nodes;
@@ -56,6 +56,7 @@ struct Builder {
     const std::vector<Prim> &prims;
     std::vector<uint32_t> idx;
     Tree tree;
+    int depth_cap = MAX_DEPTH;   // SAH splits that would make the tree deeper than this fall back to the median
     explicit Builder(const std::vector<Prim> &p) : prims(p), idx(p.size()) { for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i; }
 
     // returns the reference of the subtree over idx[first, first+count) and its box
@@ -93,7 +94,7 @@ struct Builder {
             }
         }
         uint32_t mid = 0;
-        const uint64_t cap = depth + 1 >= MAX_DEPTH ? 1ull : (1ull << (MAX_DEPTH - depth - 1));   // per-child capacity
+        const uint64_t cap = depth + 1 >= depth_cap ? 1ull : (1ull << (depth_cap - depth - 1));   // per-child capacity
         if (best_axis >= 0) {
             const float ext = cb.hi[best_axis] - cb.lo[best_axis];
             const float scale = NB / ext;
@@ -127,10 +128,14 @@ struct Builder {
 
 }  // namespace detail
 
-// Build over `prims` (boxes must already be padded).  nodes[0] is the root.
-inline Tree build(const std::vector<Prim> &prims)
+// Build over `prims` (boxes must already be padded).  nodes[0] is the root.  depth_cap (<= MAX_DEPTH) bounds
+// the number of inner-node levels: a shallower tree needs a smaller per-lane stack in LDS, which buys
+// occupancy for the latency-bound large-scene kernel.  Needs 2^depth_cap >= prims.size().
+inline Tree build(const std::vector<Prim> &prims, int depth_cap = MAX_DEPTH)
 {
     detail::Builder b(prims);
+    b.depth_cap = depth_cap < 1 ? 1 : (depth_cap > MAX_DEPTH ? MAX_DEPTH : depth_cap);
+    while (b.depth_cap < MAX_DEPTH && (1ull << b.depth_cap) < prims.size()) b.depth_cap++;
     if (prims.empty()) return b.tree;
     if (prims.size() == 1) {
         b.tree.nodes.emplace_back();

@@ -36,7 +36,6 @@ constexpr uint32_t DONE = 0xFFFFFFFFu;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr float    T_MAX = 3.402823466e+38f;   // std.math.floatMax(f32), raytracer.zig:555
 constexpr int      BLOCK = 256;
-constexpr int      CAND = 8;                   // per-lane candidate queue length (LDS)
 
 enum : uint32_t { K_LAMBERTIAN = 0, K_METAL = 1, K_DIELECTRIC = 2 };
 
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
 // through L1/L2.
 constexpr int LDS_NODE_STRIDE = 5;                    // float4 per node in LDS (4 used + 1 pad)
 
-template <int KIND, int STACK, bool HIST, bool LDSN, int NT>
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT>
 __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     const TraceParams P,
     const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 {
     typedef typename std::conditional<LDSN, uint16_t, uint32_t>::type idx_t;
     constexpr int BLOCK = NT;
-    __shared__ uint32_t s_hist[20];
+    __shared__ uint32_t s_hist[HIST ? 20 : 1];
     __shared__ idx_t s_stack[STACK * BLOCK];          // [entry][thread]: a wave's accesses are conflict-free
     __shared__ idx_t s_cand[CAND * BLOCK];
     extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
@@ -434,29 +433,31 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     // counts wave-level events, every lane its own)
     unsigned long long c_wsteps = 0, c_lsteps = 0, c_wflush = 0, c_lflush = 0, c_wshade = 0, c_lshade = 0;
 
-    // exact primitive tests for every queued candidate of every lane (wave-wide batch)
-    auto flush = [&]() {
-        for (uint32_t k = 0; __ballot(k < ncand) != 0ull; ++k) {
-            if (HIST) c_wflush += 1;
-            if (k < ncand) {
-                if (HIST) c_lflush += 1;
-                const uint32_t prim = s_cand[k * BLOCK + tid];
-                if (KIND == KIND_BVH_SPHERES) {
-                    sphere_exact(LDSN ? s_geom[prim] : geom[prim], prim, L, a, P.t_min, best_t, best);
-                } else {
-                    const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
-                    triangle_exact(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), prim, L,
-                                   P.t_min, best_t, best);
-                }
+    // One batch of exact primitive tests: every lane that holds candidates pops its newest one and tests it
+    // (the order of the tests does not matter: the closest hit is the lexicographic minimum of (t, index)).
+    // Popping one per lane keeps the batch as full as the number of lanes that hold candidates, instead of
+    // looping to the longest queue with ever fewer lanes.
+    auto test_one = [&]() {
+        if (HIST) c_wflush += 1;
+        if (ncand != 0u) {
+            if (HIST) c_lflush += 1;
+            ncand -= 1;
+            const uint32_t prim = s_cand[ncand * BLOCK + tid];
+            if (KIND == KIND_BVH_SPHERES) {
+                sphere_exact(LDSN ? s_geom[prim] : geom[prim], prim, L, a, P.t_min, best_t, best);
+            } else {
+                const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
+                triangle_exact(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), prim, L,
+                               P.t_min, best_t, best);
             }
         }
-        ncand = 0;
     };
 
     for (;;) {
         // ---- lanes whose traversal is complete: exact tests, shade, next ray --------------------------
         if (__ballot(node == DONE && (has_ray || alive)) != 0ull) {
-            flush();                                  // also tightens best_t of the lanes still traversing
+            // drain the queues of the finished lanes; lanes still traversing join each batch (their best_t tightens)
+            while (__ballot(node == DONE && ncand != 0u) != 0ull) test_one();
             if (HIST) c_wshade += 1;
             if (node == DONE) {
                 if (HIST && has_ray) c_lshade += 1;
@@ -523,11 +524,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     node = DONE;
                 }
             }
-            // a queue is nearly full somewhere: run the exact tests for the whole wave
-            // ... or enough lanes hold candidates that a batch is well filled (a hit found early tightens best_t
-            // and prunes the rest of that lane's traversal)
-            if (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull ||
-                (uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) flush();
+            // run a batch of exact tests when enough lanes hold candidates to fill it (a hit found early also
+            // tightens best_t and prunes the rest of that lane's traversal), or when a queue has no room for the
+            // two candidates a step can add
+            if ((uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) test_one();
+            while (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
             if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
         }
     }
@@ -613,11 +614,11 @@ static bool fits_lds(const DeviceScene &s, bool spheres)
     return s.bvh_depth <= 16 && s.n_nodes < 65536u && s.n_prim < 32768u && lds_scene_bytes(s, spheres) <= 40 * 1024;
 }
 
-template <int KIND, int STACK, bool HIST, bool LDSN, int NT>
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT>
 hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, float *partial, uint32_t *raycount,
                       uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
 {
-    auto kern = rt_trace_bvh_kernel<KIND, STACK, HIST, LDSN, NT>;
+    auto kern = rt_trace_bvh_kernel<KIND, STACK, CAND, HIST, LDSN, NT>;
     const size_t dyn = LDSN ? lds_scene_bytes(s, KIND == KIND_BVH_SPHERES) : 0;
     const long long grid = grid_for((const void *)kern, p, num_cus, NT, dyn);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), dyn, stream,
@@ -657,12 +658,15 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
     const bool spheres = which == RT_K_BVH_SPHERES;
     const bool lds = fits_lds(s, spheres) && !p.force_global_scene;
 #define RT_BVH(KIND)                                                                                       \
-    if (lds) return histogram ? launch_bvh<KIND, 16, true, true, 512>(RT_ARGS)                             \
-                              : launch_bvh<KIND, 16, false, true, 512>(RT_ARGS);                           \
-    if (s.bvh_depth <= 16) return histogram ? launch_bvh<KIND, 16, true, false, 256>(RT_ARGS)              \
-                                            : launch_bvh<KIND, 16, false, false, 256>(RT_ARGS);            \
-    return histogram ? launch_bvh<KIND, 32, true, false, 256>(RT_ARGS)                                     \
-                     : launch_bvh<KIND, 32, false, false, 256>(RT_ARGS);
+    if (lds) return histogram ? launch_bvh<KIND, 16, 8, true, true, 512>(RT_ARGS)                          \
+                              : launch_bvh<KIND, 16, 8, false, true, 512>(RT_ARGS);                        \
+    if (s.bvh_depth <= 16) return histogram ? launch_bvh<KIND, 16, 8, true, false, 256>(RT_ARGS)           \
+                                            : launch_bvh<KIND, 16, 8, false, false, 256>(RT_ARGS);         \
+    /* 24 stack + 7 queue words per lane = 31 KB per workgroup: five workgroups fit the CU's 160 KB */     \
+    if (s.bvh_depth <= 24) return histogram ? launch_bvh<KIND, 24, 7, true, false, 256>(RT_ARGS)           \
+                                            : launch_bvh<KIND, 24, 7, false, false, 256>(RT_ARGS);         \
+    return histogram ? launch_bvh<KIND, 32, 8, true, false, 256>(RT_ARGS)                                  \
+                     : launch_bvh<KIND, 32, 8, false, false, 256>(RT_ARGS);
     if (spheres) { RT_BVH(KIND_BVH_SPHERES) }
     RT_BVH(KIND_BVH_TRIANGLES)
 #undef RT_BVH

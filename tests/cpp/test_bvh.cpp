@@ -59,7 +59,8 @@ static void traverse(const rtbvh::Tree &t, const std::vector<Sph> &sph, const Ra
     uint32_t cand[CAND];
     uint32_t node = 0, sp = 0, ncand = 0;
     const uint32_t DONE = 0xFFFFFFFFu;
-    auto flush = [&]() { for (uint32_t k = 0; k < ncand; ++k) sphere_exact(sph[cand[k]], cand[k], r, a, t_min, best_t, best); ncand = 0; };
+    auto test_one = [&]() { if (ncand) { --ncand; sphere_exact(sph[cand[ncand]], cand[ncand], r, a, t_min, best_t, best); } };
+    auto flush = [&]() { while (ncand) test_one(); };
     while (node != DONE) {
         if (node >= t.nodes.size()) { std::printf("node index out of range\n"); std::exit(2); }
         const float *w = t.nodes[node].w;
@@ -84,7 +85,8 @@ static void traverse(const rtbvh::Tree &t, const std::vector<Sph> &sph, const Ra
         else node = DONE;
         if ((int)sp > g_max_sp) g_max_sp = (int)sp;
         if ((int)ncand > g_max_cand) g_max_cand = (int)ncand;
-        if (ncand > (uint32_t)(CAND - 2)) flush();
+        if (ncand >= 2 && (node & 1u)) test_one();          // stands for "enough lanes hold candidates": an arbitrary early batch
+        while (ncand > (uint32_t)(CAND - 2)) test_one();
     }
     flush();
 }
@@ -106,7 +108,9 @@ int main()
             if (trial % 7 == 3 && i > 0) { std::memcpy(sph[i].c, sph[0].c, sizeof sph[i].c); }   // all centres equal: degenerate SAH
             prims[i] = rtbvh::sphere_prim(sph[i].c[0], sph[i].c[1], sph[i].c[2], sph[i].r);
         }
-        const rtbvh::Tree t = rtbvh::build(prims);
+        const int cap = trial % 2 ? 12 : rtbvh::MAX_DEPTH;     // 2^12 >= every n used here: the cap must hold
+        const rtbvh::Tree t = rtbvh::build(prims, cap);
+        if (t.depth > cap) { std::printf("trial %d: depth %d exceeds the cap %d (n=%d)\n", trial, t.depth, cap, n); return 1; }
         if (!rtbvh::validate(t, prims)) { std::printf("trial %d: validate failed (n=%d)\n", trial, n); return 1; }
         const int stack_cap = t.depth <= 16 ? 16 : 32;
         for (int q = 0; q < 3000; ++q) {
