@@ -78,16 +78,22 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; RT_BENCH_BACKEND=gloo with fewer GPUs than ranks is a rehearsal mode (ranks share GPUs)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     scene, nx, ny, spp, depth, opfile = WORKLOADS[args.workload]
     spheres = R.Random_Scene(11, 0) if scene == "book" else R.Two_Sphere_Scene()
     cam = R.book_camera(nx, ny) if scene == "book" else R.BasicCamera()
-    ctx = R.Context(local_rank)
+    ctx = R.Context(device_index)
     ctx.upload_scene(spheres)
     from raytrace_amd.distributed import HipRangeRenderer, render_sample_sharded
     npix = nx * ny
