@@ -94,6 +94,9 @@ enum {
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Replaces nothing in the reference (its path is pure CPU); mirrors compute.zig:19-29 Compute.create. */
 int  rt_create(int device, rt_ctx **out);
+/* Number of GPUs rt_create accepts (the role of std.Thread.getCpuCount(), raytracer.zig:588, for
+ * rt_render_multi), or RT_E_HIP. */
+int  rt_device_count(void);
 void rt_destroy(rt_ctx *ctx);
 const char *rt_strerror(int code);
 int  rt_last_hip_error(const rt_ctx *ctx);   /* hipError_t of the last failing HIP call */
@@ -139,6 +142,16 @@ int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
  * (raytracer.zig:610-617).  n_images plays the role of getCpuCount().  rgb8 is a host buffer [ny*nx*3]. */
 int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_images,
                               uint8_t *rgb8, rt_stats *stats);
+
+/* Single-process multi-GPU form of rt_render: the thread fan-out + join + average of render_and_write
+ * (raytracer.zig:588-617) with GPUs in place of threads.  ctxs[0..n_ctx) are distinct contexts (normally one per
+ * GPU) that each hold the same uploaded scene.  GPU g traces the g-th contiguous part of [spp_begin,spp_end)
+ * (sizes differ by at most one, low g takes the extra) into its own sum buffer; the peers' buffers are copied to
+ * ctxs[0]'s GPU (xGMI peer copies), added there in GPU order (deterministic), tonemapped and returned as in
+ * rt_render.  stats: rays summed over GPUs, kernel_ms = the slowest GPU's.  Blocking.  (A job that runs one
+ * process per GPU uses rt_render_device + an RCCL reduce instead: raytrace_amd/distributed.py.) */
+int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, const rt_config *cfg,
+                    float *accum_mean, uint8_t *rgb8, rt_stats *stats);
 
 /* Device tonemap: mean = sum / spp_total; rgb8 = trunc(255.99*sqrt(mean)) (raytracer.zig:527,542-549).
  * d_mean and d_rgb8 may each be NULL; d_mean may alias d_accum_sum. */

@@ -49,7 +49,7 @@ class rt_stats(C.Structure):
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
     "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill",
-    "rt_render", "rt_render_reference_style", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
+    "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
     "rt_selftest_math",
 ]
@@ -96,6 +96,11 @@ def load():
     L.rt_last_kernel_name.restype = C.c_char_p
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
     L.rt_render.restype = C.c_int
+    L.rt_device_count.argtypes = []
+    L.rt_device_count.restype = C.c_int
+    L.rt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp,
+                                  C.POINTER(rt_stats)]
+    L.rt_render_multi.restype = C.c_int
     L.rt_render_reference_style.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), C.c_uint32, vp,
                                             C.POINTER(rt_stats)]
     L.rt_render_reference_style.restype = C.c_int

@@ -310,6 +310,33 @@ class Context:
         return od, os_, oc, ph
 
 
+def device_count():
+    """rt_device_count: GPUs visible to the library."""
+    n = _lib.load().rt_device_count()
+    if n < 0:
+        raise RtError(n, "rt_device_count")
+    return n
+
+
+def render_multi(contexts, cam, cfg):
+    """rt_render_multi: one process, several GPUs (one Context each, same scene uploaded); the sample range of
+    cfg is split across them and summed on contexts[0]'s GPU.  Blocking."""
+    if not contexts:
+        raise ValueError("render_multi needs at least one Context")
+    L = contexts[0]._L
+    n = cfg.nx * cfg.ny
+    accum = np.zeros((n, 3), np.float32)
+    rgb8 = np.zeros((n, 3), np.uint8)
+    st = rt_stats()
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = L.rt_render_multi(handles, len(contexts), C.byref(cam.to_abi()), C.byref(cfg), accum.ctypes.data,
+                           rgb8.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RtError(rc, "rt_render_multi", max(L.rt_last_hip_error(c._h) for c in contexts))
+    rays, prim, ms, hist = _stats_tuple(st)
+    return RenderResult(accum, rgb8, None, rays, prim, ms, hist)
+
+
 def write_ppm_image(fname, rgb8, nx, ny):
     """write_ppm_image, image.zig:18-37."""
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)

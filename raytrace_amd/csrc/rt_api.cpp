@@ -37,6 +37,7 @@ struct rt_ctx {
     uint32_t    *d_raycount = nullptr; size_t raycount_cap = 0;
     float       *d_mean = nullptr;   size_t mean_cap = 0;
     uint8_t     *d_rgb8 = nullptr;   size_t rgb8_cap = 0;
+    float       *d_gather = nullptr; size_t gather_cap = 0;    // rt_render_multi root: peers' sum buffers
 };
 
 namespace {
@@ -225,6 +226,13 @@ const char *rt_strerror(int code)
     }
 }
 
+int rt_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return RT_E_HIP;
+    return ndev;
+}
+
 int rt_create(int device, rt_ctx **out)
 {
     if (!out) return RT_E_ARG;
@@ -264,6 +272,7 @@ void rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->d_bvh);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_partial); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
+    (void)hipFree(ctx->d_gather);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -460,6 +469,70 @@ int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config
     HIP_TRY(ctx, rt_launch_u8_mean(ctx->d_raycount, n_images, ctx->d_rgb8, (uint32_t)(npix * 3), st));      // :616
     HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->d_rgb8, npix * 3, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (stats) *stats = total;
+    return RT_OK;
+}
+
+int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, const rt_config *cfg,
+                    float *accum_mean, uint8_t *rgb8, rt_stats *stats)
+{
+    if (!ctxs || n_ctx == 0 || n_ctx > 64 || !cam) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        if (!ctxs[g]) return RT_E_ARG;
+        for (uint32_t k = 0; k < g; ++k) if (ctxs[k] == ctxs[g]) return RT_E_ARG;
+        if (ctxs[g]->n_sph == 0 && ctxs[g]->n_tri == 0) return RT_E_STATE;
+    }
+    rt_ctx *root = ctxs[0];
+    const size_t npix = (size_t)cfg->nx * cfg->ny, nfl = npix * 3;
+    // contiguous sample ranges, sizes differ by at most one, low indices take the extra (raytracer.zig:594-600
+    // hands every thread its own samples; here GPU g owns global sample indices [b_g, e_g))
+    const uint32_t span = cfg->spp_end - cfg->spp_begin, base = span / n_ctx, extra = span % n_ctx;
+    // 1. every GPU traces its range into its own SUM buffer (launches are asynchronous: no host threads needed)
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        rt_ctx *c = ctxs[g];
+        HIP_TRY(c, hipSetDevice(c->device));
+        if ((rc = ensure(c, c->d_accum, c->accum_cap, nfl)) != RT_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, nfl * sizeof(float), c->stream));
+        rt_config sub = *cfg;
+        sub.spp_begin = cfg->spp_begin + g * base + (g < extra ? g : extra);
+        sub.spp_end = sub.spp_begin + base + (g < extra ? 1 : 0);
+        if ((rc = enqueue_trace(c, cam, &sub, c->d_accum, nullptr, c->stream)) != RT_OK) return rc;
+    }
+    // 2. the path's one exchange step: peers' buffers travel to the root GPU (xGMI peer copies, all links at once)
+    HIP_TRY(root, hipSetDevice(root->device));
+    if (n_ctx > 1 && (rc = ensure(root, root->d_gather, root->gather_cap, nfl * (n_ctx - 1))) != RT_OK) return rc;
+    if ((rc = ensure(root, root->d_mean, root->mean_cap, nfl)) != RT_OK) return rc;
+    if ((rc = ensure(root, root->d_rgb8, root->rgb8_cap, nfl)) != RT_OK) return rc;
+    for (uint32_t g = 1; g < n_ctx; ++g) {
+        rt_ctx *c = ctxs[g];
+        HIP_TRY(c, hipSetDevice(c->device));
+        float *dst = root->d_gather + (size_t)(g - 1) * nfl;
+        if (c->device == root->device)
+            HIP_TRY(c, hipMemcpyAsync(dst, c->d_accum, nfl * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        else
+            HIP_TRY(c, hipMemcpyPeerAsync(dst, root->device, c->d_accum, c->device, nfl * sizeof(float), c->stream));
+    }
+    rt_stats total; std::memset(&total, 0, sizeof total);
+    for (uint32_t g = 0; g < n_ctx; ++g) {          // join (raytracer.zig:605-607)
+        rt_ctx *c = ctxs[g];
+        HIP_TRY(c, hipSetDevice(c->device));
+        rt_stats one;
+        if ((rc = read_stats(c, c->stream, &one)) != RT_OK) return rc;
+        total.rays += one.rays; total.primary_rays += one.primary_rays;
+        if (one.kernel_ms > total.kernel_ms) total.kernel_ms = one.kernel_ms;     // GPUs run side by side
+        for (int k = 0; k < 20; ++k) total.rays_by_depth[k] += one.rays_by_depth[k];
+    }
+    // 3. root adds the peers' sums in GPU order (deterministic), tonemaps, hands the images back
+    HIP_TRY(root, hipSetDevice(root->device));
+    hipStream_t st = root->stream;
+    if (n_ctx > 1)
+        HIP_TRY(root, rt_launch_reduce_chunks(root->d_accum, root->d_gather, (uint32_t)npix, n_ctx - 1, (uint32_t)nfl, st));
+    HIP_TRY(root, rt_launch_tonemap(root->d_accum, (uint32_t)npix, cfg->spp_total, root->d_mean, root->d_rgb8, st));
+    if (accum_mean) HIP_TRY(root, hipMemcpyAsync(accum_mean, root->d_mean, nfl * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (rgb8) HIP_TRY(root, hipMemcpyAsync(rgb8, root->d_rgb8, nfl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(root, hipStreamSynchronize(st));
     if (stats) *stats = total;
     return RT_OK;
 }

@@ -264,6 +264,42 @@ def test_spp_ranges_sum_to_the_whole(gpu_ctx):
     assert empty.rays == 0 and not empty.accum.any() and not empty.raycount.any()
 
 
+def test_render_multi_contexts_split_the_samples(gpu_ctx):
+    """rt_render_multi (single-process multi-GPU form, raytracer.zig:588-617 with GPUs for threads): three
+    contexts -- on this one-GPU box all on device 0 -- take sample ranges [0,5) [5,9) [9,13); the sums are
+    gathered on the first context's GPU and added in context order."""
+    nx, ny, spp = 128, 72, 13
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp))
+    with R.Context(0) as c1, R.Context(0) as c2:
+        with pytest.raises(R.RtError) as e:                       # a context without a scene
+            R.render_multi([gpu_ctx, c1], cam, R.make_config(nx, ny, spp))
+        assert e.value.code == -4
+        c1.upload_scene(s); c2.upload_scene(s)
+        with pytest.raises(R.RtError) as e:                       # the same context twice
+            R.render_multi([gpu_ctx, c1, gpu_ctx], cam, R.make_config(nx, ny, spp))
+        assert e.value.code == -1
+        for chunk in (0, R.RT_SPP_CHUNK_AUTO):
+            cfg = R.make_config(nx, ny, spp, spp_chunk=chunk)
+            res = R.render_multi([gpu_ctx, c1, c2], cam, cfg)
+            assert res.rays == cnt["rays"] and res.primary_rays == cnt["primary_rays"]
+            assert float(np.abs(res.accum - oa).max()) <= TOL_ACCUM
+            assert psnr_u8(res.rgb8, o8) >= MIN_PSNR
+            parts = [gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_begin=b, spp_end=e_, spp_total=spp, spp_chunk=chunk))
+                     for b, e_ in ((0, 5), (5, 9), (9, 13))]
+            np.testing.assert_allclose(sum(p.accum for p in parts), res.accum, rtol=0, atol=1e-6)
+            one = R.render_multi([c2], cam, cfg)                  # n_ctx = 1 is rt_render
+            ref = c2.render(cam, cfg)
+            assert np.array_equal(one.accum.view(np.uint32), ref.accum.view(np.uint32)) and np.array_equal(one.rgb8, ref.rgb8)
+        # more contexts than samples: the extra ones trace nothing
+        few = R.render_multi([gpu_ctx, c1, c2], cam, R.make_config(nx, ny, 2))
+        ref = gpu_ctx.render(cam, R.make_config(nx, ny, 2))
+        assert few.rays == ref.rays
+        np.testing.assert_allclose(few.accum, ref.accum, rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("chunk", [1, 3, 5, 16, R.RT_SPP_CHUNK_AUTO])
 def test_sample_chunks_match_the_oracle_chunk_mode(gpu_ctx, chunk):
     """spp_chunk: samples summed per chunk of global sample indices, chunk sums added in order -- the oracle
