@@ -189,6 +189,10 @@ int rt_render_and_write(rt_ctx *ctx, const char *fname, const rt_camera *cam, co
 int rt_selftest_math(rt_ctx *ctx, uint32_t n, const float *a, const float *b,
                      float *out_div, float *out_sqrt, float *out_cbrt,
                      const uint32_t *ctr0, uint32_t *philox_out);
+/* The cbrt of random_in_unit_sphere (raytracer.zig:577) exactly as the trace kernels evaluate it (f32 fast path +
+ * guarded fallback to the musl steps), on EVERY input the path can feed it: out[k] = cbrt(k * 2^-24) for
+ * 0 <= k < 2^24 (host buffer of 2^24 floats); *n_risky = inputs that took the fallback.  Parity aid. */
+int rt_selftest_cbrt_grid(rt_ctx *ctx, float *out, uint64_t *n_risky);
 
 #ifdef __cplusplus
 }

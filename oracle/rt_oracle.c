@@ -165,6 +165,7 @@ float orc_cbrtf(float x)
     T = T * ((double)x + x + r) / (x + r + r);
     return (float)T;
 }
+void orc_cbrtf_array(const float *x, float *out, size_t n) { for (size_t k = 0; k < n; ++k) out[k] = orc_cbrtf(x[k]); }
 /* std.math.pow(f32, x, 5) (raytracer.zig:467): Zig's pow squares-and-multiplies on the frexp
  * significand (a1 = m; m2 = m*m; m4 = m2*m2; a1 *= m4) -- scaling by powers of two is exact, so
  * away from overflow/underflow this equals x * ((x*x)*(x*x)) with a rounding after each product. */

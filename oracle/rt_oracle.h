@@ -18,6 +18,7 @@
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -96,6 +97,7 @@ orc_v3 orc_normalize(orc_v3 a);
 orc_v3 orc_cross(orc_v3 a, orc_v3 b);
 uint32_t orc_argmax(orc_v3 a);
 float  orc_cbrtf(float x);                                      /* musl cbrtf == Zig std.math.cbrt(f32) */
+void   orc_cbrtf_array(const float *x, float *out, size_t n);       /* orc_cbrtf over an array (test aid) */
 float  orc_pow5(float x);
 float  orc_schlick(float cosine, float idx);
 orc_v3 orc_reflect(orc_v3 v, orc_v3 n);

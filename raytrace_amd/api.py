@@ -298,6 +298,13 @@ class Context:
         self._check(rc, "rt_render_and_write")
         return _stats_tuple(st)
 
+    def selftest_cbrt_grid(self):
+        """Production cbrt on all 2^24 inputs k * 2^-24; returns (values, number of inputs that took the fallback)."""
+        out = np.zeros(1 << 24, np.float32)
+        n = C.c_uint64(0)
+        self._check(self._L.rt_selftest_cbrt_grid(self._h, out.ctypes.data, C.byref(n)), "rt_selftest_cbrt_grid")
+        return out, int(n.value)
+
     def selftest_math(self, a, b, ctr0):
         a, b = _f32(a), _f32(b)
         ctr0 = np.ascontiguousarray(ctr0, dtype=np.uint32)

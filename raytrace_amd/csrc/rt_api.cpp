@@ -612,6 +612,29 @@ int rt_write_ppm(const char *fname, const uint8_t *rgb8, uint32_t nx, uint32_t n
     return rt::img_io::write_ppm_image(fname, rgb8, nx, ny) ? RT_OK : RT_E_IO;
 }
 
+int rt_selftest_cbrt_grid(rt_ctx *ctx, float *out, uint64_t *n_risky)
+{
+    if (!ctx || !out) return RT_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << 24;
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, n * sizeof(float) + 256));
+    unsigned long long *dc = (unsigned long long *)(d + n);
+    hipError_t e;
+    unsigned long long cnt = 0;
+    do {
+        if ((e = hipMemsetAsync(dc, 0, sizeof *dc, ctx->stream)) != hipSuccess) break;
+        if ((e = rt_launch_selftest_cbrt_grid(d, dc, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out, d, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(&cnt, dc, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return RT_E_HIP; }
+    if (n_risky) *n_risky = cnt;
+    return RT_OK;
+}
+
 int rt_selftest_math(rt_ctx *ctx, uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
                      float *out_cbrt, const uint32_t *ctr0, uint32_t *philox_out)
 {

@@ -71,6 +71,32 @@ __device__ __forceinline__ float cbrt_f32(float x)
     T = T * ((double)x + x + r) / (x + r + r);
     return (float)T;
 }
+// cbrt on the only inputs the path feeds it: x = k * 2^-24, 0 <= k < 2^24 (u32_to_unit_float).  f32 only:
+// musl's bit-hack start, two of its Halley steps in f32 (error ~2^-22), then one Newton step whose residual
+// y^3 - x is computed exactly with FMAs, so y - d carries ~43 good bits before the one final rounding.
+// cbrt_f32 rounds a value that is itself within 2^-46 of cbrt(x); the two can only round differently when the
+// true value lies within ~2^-19 ulp of a rounding midpoint.  `risky` flags everything within 2^-13 ulp of one
+// (1 input in 4096) and the caller re-evaluates those with cbrt_f32.  The result -- not this argument -- is what
+// the parity contract rests on: tests/test_gpu_parity.py compares ALL 2^24 inputs bit for bit with the oracle.
+__device__ __forceinline__ float cbrt_unit_fast(float x, bool &risky)
+{
+    float y = __uint_as_float(__float_as_uint(x) / 3u + 709958130u);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float r = (y * y) * y;
+        y = (y * __builtin_fmaf(2.0f, x, r)) * __builtin_amdgcn_rcpf(__builtin_fmaf(2.0f, r, x));
+    }
+    const float h = y * y, hl = __builtin_fmaf(y, y, -h);          // y^2 = h + hl exactly
+    const float p = h * y, pl = __builtin_fmaf(h, y, -p);          // h*y = p + pl exactly
+    const float res = (p - x) + __builtin_fmaf(hl, y, pl);         // y^3 - x
+    const float d = res * __builtin_amdgcn_rcpf(3.0f * h);
+    const float out = y - d;
+    const float dropped = (y - out) - d;                           // what the rounding of y - d lost
+    const float ulp = __uint_as_float((__float_as_uint(out) & 0x7f800000u) - (23u << 23));
+    const bool zero = x == 0.0f;
+    risky = !zero && !(__builtin_fabsf(dropped) < ulp * (0.5f - 0x1.0p-13f));
+    return zero ? 0.0f : out;
+}
 // std.math.pow(f32, x, 5) as Zig evaluates it: x * ((x*x)*(x*x)) (raytracer.zig:467)
 __device__ __forceinline__ float pow5(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x * x4; }
 

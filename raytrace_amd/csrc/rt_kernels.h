@@ -63,5 +63,6 @@ hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t
 hipError_t rt_launch_u8_sum(uint32_t *sum, const uint8_t *rgb8, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_u8_mean(const uint32_t *sum, uint32_t n_images, uint8_t *rgb8, uint32_t n, hipStream_t stream);
 
+hipError_t rt_launch_selftest_cbrt_grid(float *out, unsigned long long *n_risky, hipStream_t stream);
 hipError_t rt_launch_selftest(uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
                               float *out_cbrt, const uint32_t *ctr0, uint32_t *philox_out, hipStream_t stream);

@@ -88,7 +88,10 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
         // random_in_unit_sphere, raytracer.zig:574-578 -- once for the lambertian and the metal lanes together
         const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
         const f3 cn = cube / sqrtf(dot(cube, cube));
-        const float cb = cbrt_f32(u32_to_unit_float(r[3]));
+        const float cs = u32_to_unit_float(r[3]);
+        bool risky;
+        float cb = cbrt_unit_fast(cs, risky);                      // bit-identical to cbrt_f32 on the unit grid
+        if (__ballot(risky) != 0ull) cb = cbrt_f32(cs);            // 1 input in 4096: musl's f64 steps decide
         const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
         if (S.kind == K_LAMBERTIAN) {                              // Lambertian.scatter, :438-445
             const f3 target = (p + n) + rius;
@@ -174,6 +177,31 @@ __device__ __forceinline__ bool box_hit_fma(f3 lo, f3 hi, f3 inv, f3 noi, float 
     const float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_hi));
     tn = n;
     return n <= f;
+}
+
+// Both child boxes of a node at once with packed FMAs (v_pk_fma_f32: two FMAs per issue slot).  X/Y/Z hold one
+// axis each as {lo0, lo1, hi0, hi1} -- the layout the LDS-staged nodes use.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ void box2_hit_fma(float4 X, float4 Y, float4 Z, f3 inv, f3 noi, float t_lo, float t_hi,
+                                             bool &h0, bool &h1, float &tn0, float &tn1)
+{
+    const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
+    const v2f nx = { noi.x, noi.x }, ny = { noi.y, noi.y }, nz = { noi.z, noi.z };
+    const v2f x0 = __builtin_elementwise_fma((v2f){ X.x, X.y }, ix, nx), x1 = __builtin_elementwise_fma((v2f){ X.z, X.w }, ix, nx);
+    const v2f y0 = __builtin_elementwise_fma((v2f){ Y.x, Y.y }, iy, ny), y1 = __builtin_elementwise_fma((v2f){ Y.z, Y.w }, iy, ny);
+    const v2f z0 = __builtin_elementwise_fma((v2f){ Z.x, Z.y }, iz, nz), z1 = __builtin_elementwise_fma((v2f){ Z.z, Z.w }, iz, nz);
+    // plain hardware min/max: fminf/fmaxf would first re-canonicalise the halves taken out of the packed results
+    // (one extra v_max per operand); every input here is an FMA result or a finite bound, so there is no sNaN to quiet
+    const float n0 = hw_max3(hw_min(x0.x, x1.x), hw_min(y0.x, y1.x), hw_max(hw_min(z0.x, z1.x), t_lo));
+    const float f0 = hw_min3(hw_max(x0.x, x1.x), hw_max(y0.x, y1.x), hw_min(hw_max(z0.x, z1.x), t_hi));
+    const float n1 = hw_max3(hw_min(x0.y, x1.y), hw_min(y0.y, y1.y), hw_max(hw_min(z0.y, z1.y), t_lo));
+    const float f1 = hw_min3(hw_max(x0.y, x1.y), hw_max(y0.y, y1.y), hw_min(hw_max(z0.y, z1.y), t_hi));
+    tn0 = n0; tn1 = n1;
+    h0 = n0 <= f0; h1 = n1 <= f1;
 }
 
 enum { KIND_BRUTE_SPHERES = 0, KIND_BVH_SPHERES = 1, KIND_BVH_TRIANGLES = 2 };
@@ -408,8 +436,21 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
-        for (uint32_t k = threadIdx.x; k < n_nodes * 4u; k += NT)
-            s_scene[(k >> 2) * LDS_NODE_STRIDE + (k & 3u)] = bvh[k];
+        // one thread per node: the two child boxes are interleaved per axis, {lo0, lo1, hi0, hi1}, for the packed
+        // slab test; inner-node child refs become BYTE offsets into s_scene (one multiply per step saved; they
+        // still fit the 16-bit stack entries because the staged scene is at most 40 KB)
+        for (uint32_t k = threadIdx.x; k < n_nodes; k += NT) {
+            const float4 q0 = bvh[4u * k], q1 = bvh[4u * k + 1u], q2 = bvh[4u * k + 2u];
+            float4 q3 = bvh[4u * k + 3u];
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (!(c0 & LEAF_BIT)) q3.x = __uint_as_float(c0 * (uint32_t)(LDS_NODE_STRIDE * 16));
+            if (!(c1 & LEAF_BIT)) q3.y = __uint_as_float(c1 * (uint32_t)(LDS_NODE_STRIDE * 16));
+            float4 *dst = s_scene + k * LDS_NODE_STRIDE;
+            dst[0] = make_float4(q0.x, q1.z, q0.w, q2.y);     // x: lo0, lo1, hi0, hi1
+            dst[1] = make_float4(q0.y, q1.w, q1.x, q2.z);     // y
+            dst[2] = make_float4(q0.z, q2.x, q1.y, q2.w);     // z
+            dst[3] = q3;
+        }
         if (KIND == KIND_BVH_SPHERES)
             for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
                 s_scene[n_nodes * LDS_NODE_STRIDE + k] = geom[k];
@@ -498,11 +539,16 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if (HIST) c_wsteps += 1;
             if (node != DONE) {
                 if (HIST) c_lsteps += 1;
-                const float4 *nd = LDSN ? s_scene + node * LDS_NODE_STRIDE : bvh + 4u * node;
+                const float4 *nd = LDSN ? (const float4 *)((const char *)s_scene + node) : bvh + 4u * node;
                 const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 float tn0, tn1;
-                const bool h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
-                const bool h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
+                bool h0, h1;
+                if (LDSN) {
+                    box2_hit_fma(q0, q1, q2, inv, noi, P.t_min, best_t, h0, h1, tn0, tn1);
+                } else {
+                    h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
+                    h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
+                }
                 const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                 const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
                 if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
@@ -577,6 +623,18 @@ __global__ __launch_bounds__(256) void rt_u8_mean_kernel(const uint32_t *sum, ui
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) rgb8[k] = (uint8_t)(sum[k] / n_images);
+}
+
+// production cbrt (fast path + fallback exactly as scatter_ray uses it) on the whole unit grid k * 2^-24
+__global__ __launch_bounds__(256) void rt_selftest_cbrt_grid_kernel(float *out, unsigned long long *n_risky)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;      // grid covers exactly 2^24 threads
+    const float x = u32_to_unit_float(k << 8);
+    bool risky;
+    float cb = cbrt_unit_fast(x, risky);
+    if (__ballot(risky) != 0ull) cb = cbrt_f32(x);
+    if (risky) atomicAdd(n_risky, 1ull);
+    out[k] = cb;
 }
 
 __global__ void rt_selftest_kernel(uint32_t n, const float *a, const float *b, float *out_div, float *out_sqrt,
@@ -703,6 +761,12 @@ hipError_t rt_launch_u8_mean(const uint32_t *sum, uint32_t n_images, uint8_t *rg
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(rt_u8_mean_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, sum, n_images, rgb8, n);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_selftest_cbrt_grid(float *out, unsigned long long *n_risky, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_selftest_cbrt_grid_kernel, dim3((1u << 24) / 256u), dim3(256), 0, stream, out, n_risky);
     return hipGetLastError();
 }
 

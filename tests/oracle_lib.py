@@ -113,6 +113,8 @@ def lib():
     L.orc_argmax.restype = C.c_uint32
     L.orc_cbrtf.argtypes = [C.c_float]
     L.orc_cbrtf.restype = C.c_float
+    L.orc_cbrtf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_cbrtf_array.restype = None
     L.orc_pow5.argtypes = [C.c_float]
     L.orc_pow5.restype = C.c_float
     L.orc_schlick.argtypes = [C.c_float, C.c_float]

@@ -86,6 +86,19 @@ def test_device_math_is_bit_exact(gpu_ctx):
         assert list(out) == ph[k].tolist()
 
 
+def test_cbrt_of_the_kernels_matches_the_oracle_on_every_possible_input(gpu_ctx):
+    """random_in_unit_sphere's cbrt (raytracer.zig:577) only ever sees k * 2^-24 (u32_to_unit_float).  The trace
+    kernels evaluate it with an f32 fast path and fall back to musl's f64 steps near rounding midpoints; this
+    compares that production evaluation with the oracle's musl cbrtf on ALL 2^24 inputs, bit for bit."""
+    got, n_risky = gpu_ctx.selftest_cbrt_grid()
+    x = np.arange(1 << 24, dtype=np.float32) * np.float32(2.0 ** -24)
+    exp = np.empty_like(x)
+    O.lib().orc_cbrtf_array(x.ctypes.data, exp.ctypes.data, x.size)
+    bad = np.flatnonzero(got.view(np.uint32) != exp.view(np.uint32))
+    assert bad.size == 0, (bad.size, bad[:8], got[bad[:8]], exp[bad[:8]])
+    assert 0 < n_risky < (1 << 24) // 1024, n_risky        # the fallback is rare (about 1 input in 4096) but live
+
+
 # ---- golden vectors ----------------------------------------------------------------------------------
 def _mesh_source():
     """The golden 'mesh' scene (tests/golden/make_golden.py): four spheres tessellated 12x8."""

@@ -56,6 +56,35 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s)
                          "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(ds));
             a0 = (float)d0; a1 = (float)d1; a2 = (float)d2; a3 = (float)d3;
+        } else if (MODE == 11) { // 8 v_mad_u64_u32, accumulate form (4 independent chains, 2 each)
+                        unsigned long long r0 = i, r1 = i + 1, r2 = i + 2, r3 = i + 3;
+            unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1), u2 = __float_as_uint(a2), u3 = __float_as_uint(a3), us = __float_as_uint(s);
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %8, %0\n v_mad_u64_u32 %1, vcc, %5, %8, %1\n v_mad_u64_u32 %2, vcc, %6, %8, %2\n v_mad_u64_u32 %3, vcc, %7, %8, %3\n"
+                         "v_mad_u64_u32 %0, vcc, %4, %8, %0\n v_mad_u64_u32 %1, vcc, %5, %8, %1\n v_mad_u64_u32 %2, vcc, %6, %8, %2\n v_mad_u64_u32 %3, vcc, %7, %8, %3\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(us) : "vcc");
+            if (r0 + r1 + r2 + r3 == 12345ull) a4 += 1.0f;
+        } else if (MODE == 12) { // 8 v_rcp_f64 (4 chains, 2 each)
+            double d0 = a0 + 2.0, d1 = a1 + 2.0, d2 = a2 + 2.0, d3 = a3 + 2.0;
+            asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3\n"
+                         "v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+            if (d0 + d1 + d2 + d3 == 12345.0) a4 += 1.0f;
+        } else if (MODE == 13) { // 8 v_mul_f64
+            double d0 = a0 + 2.0, d1 = a1 + 2.0, d2 = a2 + 2.0, d3 = a3 + 2.0, ds = s;
+            asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                         "v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(ds));
+            if (d0 + d1 + d2 + d3 == 12345.0) a4 += 1.0f;
+        } else if (MODE == 14) { // 8 v_rcp_f32
+            asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                         "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 15) { // 8 v_add_f64
+            double d0 = a0 + 2.0, d1 = a1 + 2.0, d2 = a2 + 2.0, d3 = a3 + 2.0, ds = s;
+            asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                         "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(ds));
+            if (d0 + d1 + d2 + d3 == 12345.0) a4 += 1.0f;
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -64,7 +93,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s)
 template <int MODE>
 void run(const char *name, int wavesPerSimd, int instrPerIter, int laneOpsPerIter, float *d)
 {
-    const int iters = 200000;
+    const int iters = 50000;
     const int blocks = 256 * wavesPerSimd;   // 256 threads = 4 waves = 1 per SIMD per block
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1000, 1.0001f);
@@ -95,6 +124,11 @@ int main()
         run<8>("v_mad_u64_u32 (+8 cvt/xor)", w, 4, 4, d);
         run<9>("v_mul_hi_u32", w, 8, 8, d);
         run<10>("v_fma_f64 (+cvts)", w, 8, 8, d);
+        run<11>("v_mad_u64_u32 (+few)", w, 8, 8, d);
+        run<12>("v_rcp_f64 (+few)", w, 8, 8, d);
+        run<13>("v_mul_f64 (+few)", w, 8, 8, d);
+        run<14>("v_rcp_f32", w, 8, 8, d);
+        run<15>("v_add_f64 (+few)", w, 8, 8, d);
     }
     return 0;
 }
