@@ -150,6 +150,19 @@ def main():
                 traffic = d["hbm_read_bytes_counter"] + d["hbm_write_bytes"]
                 traffic_src = "profiles/latest_%s_pmc.json (FETCH_SIZE*1KiB uncorrected + WRITE_SIZE*1KiB)" % args.workload
         achieved = rays_per_step[0] * fpr / (k_ms * 1e-3) / 1e12
+        # executed (hardware-counted) VALU work of the same launch, from the same committed PMC pass: active lanes
+        # summed over all VALU instructions, against the chip's lane-issue peak (256 CU x 128 lanes x 2.4 GHz)
+        executed = None
+        if world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                d = json.load(f).get("derived", {})
+            if "valu_lane_ops_per_launch" in d:
+                lane_rate = d["valu_lane_ops_per_launch"] / (k_ms * 1e-3) / 1e12
+                executed = {"valu_T_lane_ops_per_s": lane_rate, "peak_T_lane_ops_per_s": PEAK_FP32_TFLOPS / 2,
+                            "frac": lane_rate / (PEAK_FP32_TFLOPS / 2),
+                            "valu_wave_insts_per_64_rays": d.get("valu_wave_insts_per_64_rays"),
+                            "lane_utilisation": d.get("valu_lane_utilisation"),
+                            "source": "profiles/latest_%s_pmc.json (SQ_THREAD_CYCLES_VALU, SQ_INSTS_VALU)" % args.workload}
         out = {
             "metric": "Mrays/sec (all bounces) book scene 1080p 100spp; %FP32 VALU roofline",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,6 +173,7 @@ def main():
                        "rays_per_step": rays_all, "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "executed": executed,
                          "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
                          "kernel_mrays_per_s": rays_per_step[0] / (k_ms * 1e-3) / 1e6,

@@ -80,7 +80,7 @@ int check_config(const rt_config *cfg)
     return RT_OK;
 }
 
-void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim)
+void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, bool triangles)
 {
     std::memset(&p, 0, sizeof p);
     for (int k = 0; k < 3; ++k) {
@@ -126,7 +126,9 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.n_items = (uint32_t)(pixel_items * p.n_chunks);
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
-    p.keep_traversing = 8;
+    // leave the traversal loop to test/shade when fewer lanes than this still traverse (measured on MI355X: sphere
+    // scenes from LDS 8; the triangle-mesh scene, whose steps wait on global memory, 16)
+    p.keep_traversing = triangles ? 16 : 8;
     p.flush_lanes = 24;                              // 65 = only the "queue nearly full" rule
     if (const char *e = std::getenv("RT_HIP_FLUSH_LANES")) {
         const int v = std::atoi(e);
@@ -157,7 +159,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
 {
     if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
     TraceParams p;
-    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph);
+    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;

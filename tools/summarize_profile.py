@@ -22,6 +22,9 @@ if "SQ_INSTS_VALU" in agg:
     d["valu_wave_insts_per_64_rays"] = agg["SQ_INSTS_VALU"] * 64 / rays
     d["valu_lane_utilisation"] = agg["SQ_THREAD_CYCLES_VALU"] / (agg["SQ_INSTS_VALU"] * 64)
     d["salu_per_valu"] = agg["SQ_INSTS_SALU"] / agg["SQ_INSTS_VALU"]
+    # executed VALU work: active lanes summed over every VALU instruction of one launch (SURVEY 8(d) "roofline.executed")
+    d["valu_lane_ops_per_launch"] = agg["SQ_THREAD_CYCLES_VALU"]
+    d["valu_wave_insts_per_launch"] = agg["SQ_INSTS_VALU"]
 if "FETCH_SIZE" in agg:
     # MI355X_MICROARCH.md: FETCH_SIZE (KB) reports half the bytes of wide coalesced reads on gfx950; this kernel's
     # HBM reads are the 12-byte-per-lane accum read-modify-write, so the factor is uncalibrated: both given.
