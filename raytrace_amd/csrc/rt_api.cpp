@@ -5,6 +5,7 @@
 // otherwise.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,18 @@ int ensure(rt_ctx *ctx, T *&ptr, size_t &cap, size_t need)
     return RT_OK;
 }
 
+// RN(1/y) for the kernels' div_recip (rt_device.h), or NaN when y is not eligible: the correction step is only
+// proven for a correctly rounded reciprocal of a y whose significand is not all ones, and the range keeps every
+// intermediate clear of underflow and overflow.  The host divide is IEEE (no fast-math in this build).
+float recip_for_div(float y)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &y, sizeof bits);
+    const float ay = y < 0 ? -y : y;
+    if (!(ay >= 0x1.0p-60f && ay <= 0x1.0p60f) || (bits & 0x7fffffu) == 0x7fffffu) return std::nanf("");
+    return 1.0f / y;
+}
+
 int check_config(const rt_config *cfg)
 {
     if (!cfg || cfg->nx == 0 || cfg->ny == 0) return RT_E_ARG;
@@ -89,6 +102,8 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     }
     p.sub_origin = cam->subtract_origin ? 1u : 0u;
     p.nx = cfg->nx; p.ny = cfg->ny;
+    p.inv_nx = recip_for_div((float)cfg->nx); p.inv_ny = recip_for_div((float)cfg->ny);
+    p.cam_fast = (p.inv_nx == p.inv_nx && p.inv_ny == p.inv_ny) ? 1u : 0u;
     p.spp_begin = cfg->spp_begin; p.spp_end = cfg->spp_end;
     p.max_depth = cfg->max_depth; p.t_min = cfg->t_min;
     p.key0 = (uint32_t)cfg->seed; p.key1 = (uint32_t)(cfg->seed >> 32);
@@ -319,7 +334,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
     if (mats->n >= 0x7FFFFFFFu) return RT_E_ARG;
     for (uint32_t k = 0; k < mats->n; ++k) {
         float kind_bits; std::memcpy(&kind_bits, &mats->kind[k], 4);
-        aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k], 0.0f));
+        aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k],
+                                  have_sph ? recip_for_div(sph->radius[k]) : 0.0f));
         alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], 0.0f));
     }
     if (have_sph) {

@@ -97,6 +97,16 @@ __device__ __forceinline__ float cbrt_unit_fast(float x, bool &risky)
     risky = !zero && !(__builtin_fabsf(dropped) < ulp * (0.5f - 0x1.0p-13f));
     return zero ? 0.0f : out;
 }
+// x / y, correctly rounded, from r = RN(1/y) computed once elsewhere (Markstein): q = RN(x*r) is within one ulp,
+// x - q*y is exact in one FMA, and the FMA correction lands on RN(x/y).  Valid when nothing under/overflows
+// (callers keep |x| >= 2^-100 and |x/y| far below 2^127) and y's significand is not all ones (the caller checks
+// that where r is made).  x = -0 would give +0: callers send zeros down the IEEE path.
+__device__ __forceinline__ float div_recip(float x, float y, float r)
+{
+    const float q = x * r;
+    const float rem = __builtin_fmaf(-q, y, x);
+    return __builtin_fmaf(rem, r, q);
+}
 // std.math.pow(f32, x, 5) as Zig evaluates it: x * ((x*x)*(x*x)) (raytracer.zig:467)
 __device__ __forceinline__ float pow5(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x * x4; }
 

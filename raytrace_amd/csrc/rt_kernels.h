@@ -7,6 +7,8 @@ struct TraceParams {
     float    ll[3], hz[3], vt[3], org[3];   // camera.zig:21-24
     uint32_t sub_origin;                    // camera.zig:39 vs :16
     uint32_t nx, ny;
+    float    inv_nx, inv_ny;                // RN(1/nx), RN(1/ny) for div_recip; cam_fast = 0 sends the camera ray down the IEEE divide
+    uint32_t cam_fast;
     uint32_t spp_begin, spp_end;            // global sample indices [begin, end)
     uint32_t max_depth;
     float    t_min;

@@ -62,14 +62,29 @@ struct Surface {          // HitRecord (raytracer.zig:31-36) with the material f
 // trace's per-sample prologue: raytracer.zig:537-539 and camera.zig:16/:39.  r = Philox block 0 of the sample.
 __device__ __forceinline__ void camera_ray(const TraceParams &P, Lane &L, const uint32_t r[4])
 {
-    const float u = ((float)L.i + u32_to_unit_float(r[0])) / (float)P.nx;
-    const float v = ((float)L.j + u32_to_unit_float(r[1])) / (float)P.ny;
+    // numerators are 0 or >= 2^-24 and at most ~2^24: div_recip's range conditions hold by construction
+    const float un = (float)L.i + u32_to_unit_float(r[0]), vn = (float)L.j + u32_to_unit_float(r[1]);
+    const float u = P.cam_fast ? div_recip(un, (float)P.nx, P.inv_nx) : un / (float)P.nx;
+    const float v = P.cam_fast ? div_recip(vn, (float)P.ny, P.inv_ny) : vn / (float)P.ny;
     f3 dir = mk(P.ll[0], P.ll[1], P.ll[2]) + u * mk(P.hz[0], P.hz[1], P.hz[2]) + v * mk(P.vt[0], P.vt[1], P.vt[2]);
     const f3 org = mk(P.org[0], P.org[1], P.org[2]);
     if (P.sub_origin) dir = dir - org;
     L.o = org; L.d = dir;
     L.thr = mk(1.0f, 1.0f, 1.0f);
     L.depth = 0;
+}
+
+// HitRecord.normal = (p - center) / radius (raytracer.zig:60), three correctly rounded quotients.  ax = {radius,
+// kind, param, RN(1/radius) or NaN}: with the host-made reciprocal each quotient is a multiply and two FMAs
+// (div_recip) instead of the ~11-instruction IEEE divide.  |pc| ~ |radius| at a hit point, so nothing overflows;
+// zero or tiny components (< 2^-100) and spheres without a usable reciprocal take the IEEE divide, wave-wide.
+__device__ __forceinline__ f3 sphere_normal(f3 pc, float4 ax)
+{
+    f3 n = mk(div_recip(pc.x, ax.x, ax.w), div_recip(pc.y, ax.x, ax.w), div_recip(pc.z, ax.x, ax.w));
+    const float m = fminf(fminf(__builtin_fabsf(pc.x), __builtin_fabsf(pc.y)), __builtin_fabsf(pc.z));
+    const bool slow = !(m >= 0x1.0p-100f) || !(ax.w == ax.w);
+    if (__ballot(slow) != 0ull) n = pc / ax.x;
+    return n;
 }
 
 // Material.scatter (raytracer.zig:407-414) for one lane.  unit = normalize(direction) (unused for
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
         // resolve the rays of the previous iteration and give every lane its next ray
         shade_and_spawn<HIST>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
             const float4 g = geom[prim], ax = aux[prim], al = albedo[prim];
-            S.n = (S.p - mk(g.x, g.y, g.z)) / ax.x;                // raytracer.zig:60
+            S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax);
             S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
         });
         if (__ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     } else {
                         const float4 g = LDSN ? s_geom[prim] : geom[prim];
                         mat = prim;
-                        S.n = (S.p - mk(g.x, g.y, g.z)) / aux[mat].x;   // raytracer.zig:60
+                        S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), aux[mat]);
                     }
                     const float4 ax = aux[mat], al = albedo[mat];
                     S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
@@ -642,7 +657,12 @@ __global__ void rt_selftest_kernel(uint32_t n, const float *a, const float *b, f
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    out_div[k] = a[k] / b[k];
+    // even k: the IEEE divide; odd k: div_recip with r = RN(1/b) wherever the kernels would use it (ranges as in
+    // sphere_normal / recip_for_div) -- the host compares both against its own a / b
+    const float av = __builtin_fabsf(a[k]), bv = __builtin_fabsf(b[k]);
+    const bool eligible = (k & 1u) && av >= 0x1.0p-100f && av <= 0x1.0p60f && bv >= 0x1.0p-60f && bv <= 0x1.0p60f &&
+                          (__float_as_uint(b[k]) & 0x7fffffu) != 0x7fffffu;
+    out_div[k] = eligible ? div_recip(a[k], b[k], 1.0f / b[k]) : a[k] / b[k];
     out_sqrt[k] = sqrtf(a[k]);
     out_cbrt[k] = cbrt_f32(a[k]);
     uint32_t r[4];
