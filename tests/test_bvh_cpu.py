@@ -15,3 +15,13 @@ def test_bvh_builder_and_traversal(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok:"), out.stdout
+
+
+def test_reciprocal_division_equals_ieee(tmp_path):
+    """div_recip (rt_device.h) on the host: random operands and the camera / sphere-normal shapes."""
+    exe = str(tmp_path / "test_div_recip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "test_div_recip.cpp"),
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok:"), out.stdout
