@@ -117,8 +117,9 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     const uint32_t n_spp = cfg->spp_end - cfg->spp_begin;
     const uint64_t pixel_items = (uint64_t)p.tiles_x * tiles_y * 64u;
     if (chunk == RT_SPP_CHUNK_AUTO) {
-        // enough items to keep the tail short (>= ~16 per lane of a full chip), chunks of at least 4 samples
-        const uint64_t want_items = 64ull * 256 * 2048;
+        // enough items to keep the tail short (~80 per lane of a full chip; measured on C3: 10 planes run as fast
+        // as 17 or 25 and write less), chunks of at least 4 samples
+        const uint64_t want_items = 64ull * 256 * 1280;
         chunk = 0;
         if (n_spp >= 8 && pixel_items < want_items) {
             uint64_t nc = (want_items + pixel_items - 1) / pixel_items;
