@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")   # RT_HIP_LIB: another build of the same library (dev aid)
 
 RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
 RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2

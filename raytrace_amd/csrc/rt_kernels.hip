@@ -50,6 +50,9 @@ struct Lane {
     uint32_t part;        // chunk slot (index of the partial-sum plane) when samples are chunked
     uint32_t depth;
     uint32_t nrays;       // world.hit evaluations of this pixel
+    // the lane's NEXT work item, already dequeued and decoded (NOPIX = none); see advance()
+    uint32_t nx_pix, nx_i, nx_j, nx_part;
+    bool     dry;         // the queue handed this lane an item beyond the end: it will get no more
 };
 
 struct Surface {          // HitRecord (raytracer.zig:31-36) with the material flattened
@@ -234,7 +237,7 @@ struct Outputs {
 // pixel is done -- it writes the pixel out and pulls the next pixel from the global queue (one
 // wave-aggregated atomic for all lanes of the wave that need one).  Render's loops, raytracer.zig:521-528,
 // and trace's, :536-541.  Returns true when a camera ray is to be generated for (L.pix, L.sample).
-__device__ __forceinline__ bool advance(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane)
+__device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane)
 {
     if (L.sample >= L.send) {
         if (L.pix != NOPIX) {                         // (pixel, sample range) finished: this lane is its only writer
@@ -307,12 +310,105 @@ __device__ __forceinline__ bool advance(const TraceParams &P, Lane &L, bool &ali
     return L.pix != NOPIX && L.sample < L.send;
 }
 
+// advance_direct's job with the dequeue done for the whole wave at once and one item ahead (brute-force kernel).
+// Some lane finishes an item in nearly every
+// shading pass (2-3 of 64), so a dequeue + decode done by the finishing lanes alone would run on every pass with
+// the wave almost empty.  Instead every lane keeps its NEXT item decoded in registers; a finishing lane just
+// switches to it, and only when a lane finds that slot empty does the wave refill the empty slots of ALL its
+// lanes in one go (about every 15th pass).  Called by all lanes that take part in the shading pass.
+// Every wave owns a reserved range of items [next, end) in LDS, touched only by its leader lane; the lanes take
+// consecutive items from it (ballot + popcount rank), and only when the range runs dry does the leader reserve
+// the next P.queue_batch items with ONE atomic on the global head.  (One atomic per item saturates a single
+// counter at this kernel's rate.)
+__device__ __forceinline__ bool advance_prefetch(const TraceParams &P, Lane &L, bool idle, bool &alive, Outputs &O, uint32_t lane)
+{
+    const bool fin = idle && L.sample >= L.send;
+    if (fin && L.pix != NOPIX) {                      // item finished: this lane is its only writer
+        if (P.n_chunks > 1u) {
+            float *dst = O.partial + (size_t)L.part * P.plane_stride + 3ull * L.pix;
+            dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
+            if (O.raycount) atomicAdd(&O.raycount[L.pix], L.nrays);
+        } else {
+            float *dst = O.accum + 3ull * L.pix;
+            dst[0] += L.col.x; dst[1] += L.col.y; dst[2] += L.col.z;
+            if (O.raycount) O.raycount[L.pix] += L.nrays;
+        }
+        O.my_rays += L.nrays;
+        L.pix = NOPIX;
+    }
+    if (__ballot(fin && L.nx_pix == NOPIX && !L.dry) != 0ull) {     // wave-uniform: refill every empty slot
+        const bool take = L.nx_pix == NOPIX && !L.dry;
+        const unsigned long long m = __ballot(take);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+        uint32_t q_next = 0, q_avail = 0, q_new = 0;
+        if (lane == leader) {
+            uint32_t *wq = O.wave_queue;
+            q_next = wq[0];
+            q_avail = wq[1] - q_next;
+            if (cnt > q_avail) {
+                q_new = atomicAdd(O.queue, P.queue_batch);
+                wq[0] = q_new + (cnt - q_avail);
+                wq[1] = q_new + P.queue_batch;
+            } else {
+                wq[0] = q_next + cnt;
+            }
+        }
+        q_next = __builtin_amdgcn_readlane(q_next, leader);    // leader is wave-uniform (from the ballot)
+        q_avail = __builtin_amdgcn_readlane(q_avail, leader);
+        q_new = __builtin_amdgcn_readlane(q_new, leader);
+        if (take) {
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t item = rank < q_avail ? q_next + rank : q_new + (rank - q_avail);
+            if (item >= P.n_items) {
+                L.dry = true;
+            } else {
+                // item -> (tile, chunk, pixel): 8x8 tiles, row-major inside a tile, so a wave starts on one
+                // coherent tile; the chunks of a tile are consecutive items
+                const uint32_t slot = item >> 6, within = item & 63u;
+                const uint32_t tile = slot / P.n_chunks, part = slot - tile * P.n_chunks;
+                const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                const uint32_t i = P.x0 + tx * 8u + (within & 7u);
+                const uint32_t jr = P.y0 + ty * 8u + (within >> 3);
+                if (i < P.x1 && jr < P.y1) {          // (tiles may overhang the rect: such an item is empty)
+                    L.nx_pix = jr * P.nx + i;         // raytracer.zig:521-528 output index
+                    L.nx_i = i;
+                    L.nx_j = P.q3 ? (P.ny - jr) : (P.ny - 1u - jr);   // raytracer.zig:523
+                    L.nx_part = part;
+                }
+            }
+        }
+    }
+    if (fin) {
+        if (L.nx_pix != NOPIX) {
+            L.pix = L.nx_pix; L.i = L.nx_i; L.j = L.nx_j; L.part = L.nx_part;
+            L.nx_pix = NOPIX;
+            if (P.n_chunks > 1u) {                    // chunk k covers global samples [k*C, (k+1)*C)
+                const uint32_t k = P.chunk0 + L.part;
+                const uint32_t lo = k * P.spp_chunk, hi = lo + P.spp_chunk;
+                L.sample = lo > P.spp_begin ? lo : P.spp_begin;
+                L.send = hi < P.spp_end ? hi : P.spp_end;
+            } else {
+                L.sample = P.spp_begin;
+                L.send = P.spp_end;
+            }
+            L.col = mk(0, 0, 0);
+            L.nrays = 0;
+        } else if (L.dry) {
+            alive = false;                            // queue drained
+        }
+    }
+    return idle && L.pix != NOPIX && L.sample < L.send;
+}
+// (The BVH kernels keep advance_direct: there the same change left the VALU count where it was and cost 3 % in
+// time -- measured, profiles/ notes in DESIGN.md -- while the brute-force kernel gained 15 %.)
+
 // Everything between two world.hit calls of a lane: the rest of color() after the hit test
 // (raytracer.zig:555-571) for a lane whose ray is resolved (best/best_t), and the next ray of the lane --
 // the scattered ray, or the camera ray of its next sample when the path ended.  The two cases need
 // different Philox blocks but never both in one lane, so ONE Philox evaluation serves the whole wave.
 // A metal-absorbed lane (1 in 10^4 rays) simply gets its camera ray in the next pass.
-template <bool HIST, class SurfaceFn>
+template <bool HIST, bool PREFETCH, class SurfaceFn>
 __device__ __forceinline__ void shade_and_spawn(const TraceParams &P, Lane &L, bool &alive, bool &has_ray, Outputs &O,
                                                 uint32_t lane, float a, float best_t, uint32_t best,
                                                 uint32_t *s_hist, SurfaceFn fetch_surface)
@@ -341,7 +437,8 @@ __device__ __forceinline__ void shade_and_spawn(const TraceParams &P, Lane &L, b
         if (!scatter) { L.sample += 1; has_ray = false; }
     }
     bool gen = false;
-    if (!has_ray && alive) gen = advance(P, L, alive, O, lane);
+    if (PREFETCH) gen = advance_prefetch(P, L, !has_ray && alive, alive, O, lane);
+    else if (!has_ray && alive) gen = advance_direct(P, L, alive, O, lane);
     if (scatter || gen) {
         uint32_t r[4];
         philox4x32_10(L.pix, L.sample, scatter ? L.depth + 1u : 0u, 0u, P.key0, P.key1, r);
@@ -381,6 +478,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     Lane L;
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
     L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = 0; L.send = 0; L.part = 0; L.depth = 0; L.nrays = 0;
+    L.nx_pix = NOPIX; L.nx_i = 0; L.nx_j = 0; L.nx_part = 0; L.dry = false;
     bool alive = true, has_ray = false;
     Outputs O{ accum, partial, raycount, queue, s_wq + 2 * (threadIdx.x >> 6), 0ull, 0ull };
 
@@ -388,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     uint32_t best = NOHIT;
     for (;;) {
         // resolve the rays of the previous iteration and give every lane its next ray
-        shade_and_spawn<HIST>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+        shade_and_spawn<HIST, true>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
             const float4 g = geom[prim], ax = aux[prim], al = albedo[prim];
             S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax);
             S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
@@ -477,6 +575,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     Lane L;
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.thr = mk(0, 0, 0); L.col = mk(0, 0, 0);
     L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = 0; L.send = 0; L.part = 0; L.depth = 0; L.nrays = 0;
+    L.nx_pix = NOPIX; L.nx_i = 0; L.nx_j = 0; L.nx_part = 0; L.dry = false;
     bool alive = true, has_ray = false;
     Outputs O{ accum, partial, raycount, queue, s_wq + 2 * (threadIdx.x >> 6), 0ull, 0ull };
 
@@ -517,7 +616,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if (HIST) c_wshade += 1;
             if (node == DONE) {
                 if (HIST && has_ray) c_lshade += 1;
-                shade_and_spawn<HIST>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+                shade_and_spawn<HIST, false>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
                     uint32_t mat;
                     if (KIND == KIND_BVH_TRIANGLES) {
                         const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];

@@ -13,7 +13,7 @@ import raytrace_amd._lib as l
 l.LIB_PATH = os.path.abspath(sys.argv[1])
 import raytrace_amd as R
 ctx = R.Context(0)
-nx, ny, spp = 1920, 1080, 100
+nx, ny, spp = 1920, 1080, int(os.environ.get('VAR_SPP', '100'))
 ctx.upload_scene(R.Random_Scene(11, 0))
 cam = R.book_camera(nx, ny)
 cfg = R.make_config(nx, ny, spp, spp_chunk=R.RT_SPP_CHUNK_AUTO)
