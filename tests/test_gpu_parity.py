@@ -218,6 +218,52 @@ def test_large_random_sphere_scenes(gpu_ctx):
         _compare(res, oa, o8, orc, cnt)
 
 
+@pytest.mark.parametrize("cap", ["12", "16", "24", "32"])
+def test_bvh_depth_cap_variants_of_the_triangle_kernel(gpu_ctx, monkeypatch, cap):
+    """The triangle kernel has one instantiation per stack size (depth <= 16 / 24 / 32) and the builder's depth
+    cap decides which runs; a cap below the SAH depth also exercises its median-split fallback.  A mesh of
+    27 000 triangles, same image whatever the tree."""
+    src = R.Spheres(cx=[0, 0, -1.1, 1.1, 0.3], cy=[0, -100.5, 0, 0, 0.9], cz=[-1, -1, -1, -1, -1.2],
+                    radius=[0.5, 100, 0.5, 0.5, 0.3], kind=[0, 0, 2, 1, 0], r=[.5, .5, .95, .8, .2], g=[.5, .5, .95, .6, .7],
+                    b=[.5, .5, .95, .2, .3], param=[0, 0, 1.5, .15, 0])
+    tris = R.Tessellate_Spheres(src, 60, 45)
+    monkeypatch.setenv("RT_HIP_BVH_DEPTH_CAP", cap)
+    gpu_ctx.upload_scene(triangles=tris, materials=src)
+    info = gpu_ctx.scene_info()
+    min_depth = int(np.ceil(np.log2(len(tris))))             # 15: a cap below it is raised to what the mesh needs
+    assert info["n_triangles"] == len(tris) and info["bvh_depth"] <= max(int(cap), min_depth)
+    nx, ny, spp = 96, 54, 4
+    res = gpu_ctx.render(R.BasicCamera(), R.make_config(nx, ny, spp), want_raycount=True)
+    w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(src))
+    oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(nx, ny, spp))
+    _compare(res, oa, o8, orc, cnt)
+
+
+def test_sphere_scene_too_big_for_lds_and_radii_without_a_fast_reciprocal(gpu_ctx):
+    """(a) Random_Scene(14): ~500 spheres do not fit the LDS-staged variant, the global-memory BVH kernel runs.
+    (b) radii whose reciprocal the host refuses to precompute (all-ones significand, far outside 2^+-60) and a
+    negative radius: the hit normal then takes the IEEE divide; results must not care."""
+    s = R.Random_Scene(14, 3)
+    assert len(s) > 450
+    gpu_ctx.upload_scene(s)
+    cam, ocam = R.book_camera(120, 68), O.book_camera(120, 68)
+    res = gpu_ctx.render(cam, R.make_config(120, 68, 4), want_raycount=True)
+    w = O.World(spheres=spheres_to_oracle(s))
+    _compare(res, *O.render_counter(w, ocam, O.make_config(120, 68, 4)))
+    allones = float(np.frombuffer(np.uint32(0x3EFFFFFF).tobytes(), np.float32)[0])      # 0.49999997
+    odd = R.Spheres(cx=[0, 0, -1.2, 1.2], cy=[0, -100.5, 0, 0], cz=[-1, -1, -1, -1], radius=[allones, 100, -0.45, 0.5],
+                    kind=[0, 0, 2, 1], r=[.5, .5, .95, .8], g=[.5, .5, .95, .6], b=[.5, .5, .95, .2], param=[0, 0, 1.5, .1])
+    for flavour in ("brute", "bvh"):
+        gpu_ctx.set_flags(FLAVOURS[flavour])
+        try:
+            gpu_ctx.upload_scene(odd)
+            res = gpu_ctx.render(R.BasicCamera(), R.make_config(96, 54, 6), want_raycount=True)
+        finally:
+            gpu_ctx.set_flags(0)
+        w = O.World(spheres=spheres_to_oracle(odd))
+        _compare(res, *O.render_counter(w, O.camera_basic(), O.make_config(96, 54, 6)))
+
+
 @pytest.mark.parametrize("name,spp", [("two", 100), ("book", 100)])
 def test_full_size_1080p_sampled_pixels(gpu_ctx, name, spp):
     """configs[1] / configs[2] at full size: the counter RNG makes every pixel independent, so the
