@@ -14,15 +14,22 @@ from helpers import spheres_to_oracle, psnr_u8
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 scene, nx, ny, spp, depth = {"c3": ("book", 1920, 1080, 100, 16), "c2": ("two", 1920, 1080, 100, 16),
-                             "c1": ("book", 400, 225, 10, 10)}[name]
-s = R.Random_Scene(11, 0) if scene == "book" else R.Two_Sphere_Scene()
-cam = R.book_camera(nx, ny) if scene == "book" else R.BasicCamera()
-ocam = O.book_camera(nx, ny) if scene == "book" else O.camera_basic()
+                             "c1": ("book", 400, 225, 10, 10),
+                             # configs[3]: the tessellated book scene
+                             "c4": ("mesh", 1920, 1080, 256, 16)}[name]
+s = R.Two_Sphere_Scene() if scene == "two" else R.Random_Scene(11, 0)
+cam = R.BasicCamera() if scene == "two" else R.book_camera(nx, ny)
+ocam = O.camera_basic() if scene == "two" else O.book_camera(nx, ny)
 ctx = R.Context(0)
-ctx.upload_scene(s)
+if scene == "mesh":
+    from helpers import triangles_to_oracle
+    tris = R.Tessellate_Spheres(s, 0, 0)
+    ctx.upload_scene(triangles=tris, materials=s)
+else:
+    ctx.upload_scene(s)
 res = ctx.render(cam, R.make_config(nx, ny, spp, max_depth=depth, spp_chunk=R.RT_SPP_CHUNK_AUTO), want_raycount=True)
 print("GPU: %d rays, kernel %.2f ms" % (res.rays, res.kernel_ms), flush=True)
-w = O.World(spheres=spheres_to_oracle(s))
+w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(s)) if scene == "mesh" else O.World(spheres=spheres_to_oracle(s))
 auto_chunk = 0
 # the oracle's chunk mode must mirror the GPU's AUTO choice to compare sums in the same order; the tolerance does
 # not need it, so the plain running sum is used and the difference stays within a few 1e-7
@@ -45,7 +52,7 @@ out = {"config": name, "nx": nx, "ny": ny, "spp": spp, "max_depth": depth, "pixe
        "gpu_rays": int(res.rays), "oracle_rays": rays, "raycount_mismatching_pixels": rc_bad,
        "max_abs_err_linear_mean": max_err, "rgb8_values_differing": u8_bad,
        "psnr_db": None if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), "oracle_seconds": time.time() - t0,
-       "oracle": "list traversal (normative), counter RNG seed 1, 16 host threads"}
+       "oracle": "%s, counter RNG seed 1, 16 host threads" % ("triangle list semantics via the oracle's own BVH" if scene == "mesh" else "list traversal (normative)")}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_parity_%s.json" % name), "w"), indent=1)
 print(json.dumps(out))
