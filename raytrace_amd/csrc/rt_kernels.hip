@@ -2,9 +2,11 @@
 // (raytracer.zig:517-572) as one persistent wave64 kernel, in three intersection flavours.
 //
 // Shape of the kernel
-//   * persistent workers: the grid is sized to fill the chip once; every lane owns one pixel at a
-//     time and walks its samples in order (so the per-pixel sum has the reference's order), pulling
-//     the next pixel from a global queue with one wave-aggregated atomic (ballot + popcount).
+//   * persistent workers: the grid is sized to fill the chip once; every lane owns one work item at a
+//     time -- a pixel, or one chunk of a pixel's global sample indices (rt_config.spp_chunk) -- and walks
+//     its samples in order, so every sum has a fixed order.  Items come from a global queue in
+//     wave-reserved ranges (one atomic per 64-128 items); chunk sums land in per-chunk planes that a
+//     second kernel adds in sample order.
 //   * the recursion of color() is a per-lane state machine: one outer iteration = one world.hit.
 //     A lane whose path ended (miss, absorbed, depth cap) regenerates its next camera ray in the
 //     same iteration, so every lane of the wave carries a live ray into the intersection step
@@ -17,7 +19,9 @@
 //     boxes); leaves are queued per lane and the exact primitive tests run in wave-wide batches, so
 //     the expensive IEEE sqrt/divide code is executed by many lanes at once instead of once per
 //     divergent leaf visit.  The answer is the list traversal's closest hit (raytracer.zig:92-113):
-//     lexicographic minimum of (t, primitive index).
+//     lexicographic minimum of (t, primitive index).  Traversal and shading are decoupled: finished
+//     lanes are shaded and restarted at the root while the stragglers keep traversing.  Small scenes
+//     are staged in LDS (boxes interleaved for packed FMAs), large ones are read through L1/L2.
 //   * no MFMA: this is branchy f32 VALU work.
 //
 // Arithmetic contract: see rt_device.h.
