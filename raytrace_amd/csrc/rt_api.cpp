@@ -83,7 +83,9 @@ int check_config(const rt_config *cfg)
     if (cfg->max_depth > 1000000u) return RT_E_ARG;
     if (cfg->spp_chunk != 0 && cfg->spp_chunk != RT_SPP_CHUNK_AUTO) {
         const uint64_t nc = ((uint64_t)cfg->spp_end + cfg->spp_chunk - 1) / cfg->spp_chunk - cfg->spp_begin / cfg->spp_chunk;
-        if (nc > 4096 || nc * ((uint64_t)cfg->nx * cfg->ny + 4096) * 64 > 0xFFFFFFFFull) return RT_E_ARG;
+        const uint64_t tile_slots = (((uint64_t)cfg->nx + 7) / 8) * (((uint64_t)cfg->ny + 7) / 8) * 64;   // 8x8 tiles
+        // work items fit 32 bits, with room for the reservations the waves make past the end of the queue
+        if (nc > 4096 || nc * tile_slots > 0xFF000000ull) return RT_E_ARG;
     }
     const bool whole = !cfg->tile_x0 && !cfg->tile_y0 && !cfg->tile_x1 && !cfg->tile_y1;
     if (!whole) {

@@ -381,6 +381,20 @@ def test_sample_chunks_match_the_oracle_chunk_mode(gpu_ctx, chunk):
     assert np.array_equal(tile.accum.reshape(ny, nx, 3)[m].view(np.uint32), full.accum.reshape(ny, nx, 3)[m].view(np.uint32))
 
 
+def test_many_small_chunks_at_full_resolution(gpu_ctx):
+    """1920x1080 with one-sample chunks: 83 M work items (the bound is on items fitting 32 bits, not on pixels x 64)."""
+    nx, ny, spp = 1920, 1080, 40
+    s, cam, _ = _scene("two", nx, ny)
+    gpu_ctx.upload_scene(s)
+    a = gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=1), want_raycount=True)
+    b = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    assert a.rays == b.rays and np.array_equal(a.raycount, b.raycount)
+    np.testing.assert_allclose(a.accum, b.accum, rtol=0, atol=2e-6)
+    with pytest.raises(R.RtError) as e:                       # 4097 chunks: more planes than the library allows
+        gpu_ctx.render(cam, R.make_config(64, 64, 5000, spp_chunk=1))
+    assert e.value.code == _lib.RT_E_ARG
+
+
 def test_tiles_equal_the_subrectangle(gpu_ctx):
     nx, ny, spp = 100, 60, 4
     s, cam, _ = _scene("book", nx, ny)
