@@ -132,7 +132,7 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     }
     p.spp_chunk = 0; p.chunk0 = 0; p.n_chunks = 1;
     if (chunk != 0 && n_spp > 0) {
-        const uint32_t c0 = cfg->spp_begin / chunk, c1 = (cfg->spp_end + chunk - 1) / chunk;
+        const uint32_t c0 = cfg->spp_begin / chunk, c1 = (uint32_t)(((uint64_t)cfg->spp_end + chunk - 1) / chunk);
         if (c1 - c0 > 1) { p.spp_chunk = chunk; p.chunk0 = c0; p.n_chunks = c1 - c0; }
     }
     p.plane_stride = (size_t)cfg->nx * cfg->ny * 3;
