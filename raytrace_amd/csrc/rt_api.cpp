@@ -52,6 +52,15 @@ namespace {
         }                                                    \
     } while (0)
 
+// Nothing may throw across the C boundary (include/rt_hip.h): host-side allocation failures become RT_E_NOMEM.
+template <class F>
+int guarded(F &&body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc &) { return RT_E_NOMEM; }
+    catch (...) { return RT_E_STATE; }
+}
+
 template <typename T>
 int ensure(rt_ctx *ctx, T *&ptr, size_t &cap, size_t need)
 {
@@ -327,62 +336,64 @@ static bool spheres_valid(const rt_spheres *s, bool need_geometry)
 
 int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri, const rt_spheres *materials)
 {
-    if (!ctx) return RT_E_ARG;
-    const bool have_sph = sph && sph->n, have_tri = tri && tri->n;
-    if (have_sph == have_tri) return RT_E_ARG;            // exactly one kind of primitive per scene
-    std::vector<float4> geom, tris, aux, alb;
-    std::vector<rtbvh::Prim> prims;
-    const rt_spheres *mats = have_sph ? sph : materials;
-    if (!spheres_valid(mats, have_sph)) return RT_E_ARG;
-    if (mats->n >= 0x7FFFFFFFu) return RT_E_ARG;
-    for (uint32_t k = 0; k < mats->n; ++k) {
-        float kind_bits; std::memcpy(&kind_bits, &mats->kind[k], 4);
-        aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k],
-                                  have_sph ? recip_for_div(sph->radius[k]) : 0.0f));
-        alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], 0.0f));
-    }
-    if (have_sph) {
-        for (uint32_t k = 0; k < sph->n; ++k) {
-            const float rad = sph->radius[k];
-            geom.push_back(make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad));   // raytracer.zig:51
-            prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
+    return guarded([&]() -> int {
+        if (!ctx) return RT_E_ARG;
+        const bool have_sph = sph && sph->n, have_tri = tri && tri->n;
+        if (have_sph == have_tri) return RT_E_ARG;            // exactly one kind of primitive per scene
+        std::vector<float4> geom, tris, aux, alb;
+        std::vector<rtbvh::Prim> prims;
+        const rt_spheres *mats = have_sph ? sph : materials;
+        if (!spheres_valid(mats, have_sph)) return RT_E_ARG;
+        if (mats->n >= 0x7FFFFFFFu) return RT_E_ARG;
+        for (uint32_t k = 0; k < mats->n; ++k) {
+            float kind_bits; std::memcpy(&kind_bits, &mats->kind[k], 4);
+            aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k],
+                                      have_sph ? recip_for_div(sph->radius[k]) : 0.0f));
+            alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], 0.0f));
         }
-    } else {
-        if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= 0x7FFFFFFFu / 3) return RT_E_ARG;
-        for (uint32_t k = 0; k < tri->n; ++k) {
-            if (tri->material[k] >= mats->n) return RT_E_ARG;
-            const float *a = tri->v0 + 3 * (size_t)k, *b = tri->v1 + 3 * (size_t)k, *c = tri->v2 + 3 * (size_t)k;
-            float mat_bits; std::memcpy(&mat_bits, &tri->material[k], 4);
-            tris.push_back(make_float4(a[0], a[1], a[2], mat_bits));
-            tris.push_back(make_float4(b[0], b[1], b[2], 0.0f));
-            tris.push_back(make_float4(c[0], c[1], c[2], 0.0f));
-            prims.push_back(rtbvh::triangle_prim(a, b, c));
+        if (have_sph) {
+            for (uint32_t k = 0; k < sph->n; ++k) {
+                const float rad = sph->radius[k];
+                geom.push_back(make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad));   // raytracer.zig:51
+                prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
+            }
+        } else {
+            if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= 0x7FFFFFFFu / 3) return RT_E_ARG;
+            for (uint32_t k = 0; k < tri->n; ++k) {
+                if (tri->material[k] >= mats->n) return RT_E_ARG;
+                const float *a = tri->v0 + 3 * (size_t)k, *b = tri->v1 + 3 * (size_t)k, *c = tri->v2 + 3 * (size_t)k;
+                float mat_bits; std::memcpy(&mat_bits, &tri->material[k], 4);
+                tris.push_back(make_float4(a[0], a[1], a[2], mat_bits));
+                tris.push_back(make_float4(b[0], b[1], b[2], 0.0f));
+                tris.push_back(make_float4(c[0], c[1], c[2], 0.0f));
+                prims.push_back(rtbvh::triangle_prim(a, b, c));
+            }
         }
-    }
-    int depth_cap = 24;                                        // 24-entry stacks: 5 workgroups per CU instead of 3
-    if (const char *e = std::getenv("RT_HIP_BVH_DEPTH_CAP")) { const int v = std::atoi(e); if (v >= 8 && v <= 32) depth_cap = v; }
-    const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
-    if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
-    std::vector<float4> nodes(tree.nodes.size() * 4);
-    if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));
+        int depth_cap = 24;                                        // 24-entry stacks: 5 workgroups per CU instead of 3
+        if (const char *e = std::getenv("RT_HIP_BVH_DEPTH_CAP")) { const int v = std::atoi(e); if (v >= 8 && v <= 32) depth_cap = v; }
+        const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
+        if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
+        std::vector<float4> nodes(tree.nodes.size() * 4);
+        if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));
 
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
-    (void)hipFree(ctx->d_bvh);
-    ctx->d_geom = ctx->d_tri = ctx->d_aux = ctx->d_albedo = ctx->d_bvh = nullptr;
-    ctx->n_sph = ctx->n_tri = ctx->n_nodes = 0; ctx->bvh_depth = 0;
-    int rc;
-    if ((rc = upload_vec(ctx, ctx->d_geom, geom)) != RT_OK) return rc;
-    if ((rc = upload_vec(ctx, ctx->d_tri, tris)) != RT_OK) return rc;
-    if ((rc = upload_vec(ctx, ctx->d_aux, aux)) != RT_OK) return rc;
-    if ((rc = upload_vec(ctx, ctx->d_albedo, alb)) != RT_OK) return rc;
-    if ((rc = upload_vec(ctx, ctx->d_bvh, nodes)) != RT_OK) return rc;
-    ctx->n_sph = have_sph ? sph->n : 0;
-    ctx->n_tri = have_tri ? tri->n : 0;
-    ctx->n_nodes = (uint32_t)tree.nodes.size();
-    ctx->bvh_depth = tree.depth;
-    return RT_OK;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
+        (void)hipFree(ctx->d_bvh);
+        ctx->d_geom = ctx->d_tri = ctx->d_aux = ctx->d_albedo = ctx->d_bvh = nullptr;
+        ctx->n_sph = ctx->n_tri = ctx->n_nodes = 0; ctx->bvh_depth = 0;
+        int rc;
+        if ((rc = upload_vec(ctx, ctx->d_geom, geom)) != RT_OK) return rc;
+        if ((rc = upload_vec(ctx, ctx->d_tri, tris)) != RT_OK) return rc;
+        if ((rc = upload_vec(ctx, ctx->d_aux, aux)) != RT_OK) return rc;
+        if ((rc = upload_vec(ctx, ctx->d_albedo, alb)) != RT_OK) return rc;
+        if ((rc = upload_vec(ctx, ctx->d_bvh, nodes)) != RT_OK) return rc;
+        ctx->n_sph = have_sph ? sph->n : 0;
+        ctx->n_tri = have_tri ? tri->n : 0;
+        ctx->n_nodes = (uint32_t)tree.nodes.size();
+        ctx->bvh_depth = tree.depth;
+        return RT_OK;
+    });
 }
 
 int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
@@ -560,11 +571,13 @@ int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, c
 
 int rt_render_and_write(rt_ctx *ctx, const char *fname, const rt_camera *cam, const rt_config *cfg, rt_stats *stats)
 {
-    if (!fname || !cfg) return RT_E_ARG;
-    std::vector<uint8_t> img((size_t)cfg->nx * cfg->ny * 3);
-    const int rc = rt_render(ctx, cam, cfg, nullptr, img.data(), nullptr, stats);
-    if (rc != RT_OK) return rc;
-    return rt_write_ppm(fname, img.data(), cfg->nx, cfg->ny);
+    return guarded([&]() -> int {
+        if (!fname || !cfg) return RT_E_ARG;
+        std::vector<uint8_t> img((size_t)cfg->nx * cfg->ny * 3);
+        const int rc = rt_render(ctx, cam, cfg, nullptr, img.data(), nullptr, stats);
+        if (rc != RT_OK) return rc;
+        return rt_write_ppm(fname, img.data(), cfg->nx, cfg->ny);
+    });
 }
 
 // ---- host-side mirrors ------------------------------------------------------------------------
@@ -587,50 +600,58 @@ void rt_camera_set_position(rt_camera *cam, const float lookfrom[3], const float
 int rt_random_scene(uint32_t half_size, uint64_t seed, uint32_t cap, float *cx, float *cy, float *cz, float *radius,
                     uint32_t *kind, float *r, float *g, float *b, float *param)
 {
-    rt::RndGen rng = rt::RndGen::init(seed);
-    const rt::Hittable world = rt::Random_Scene(half_size, rng);
-    if (world.objects.size() > cap) return RT_E_CAP;
-    if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
-    soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
-    return (int)world.objects.size();
+    return guarded([&]() -> int {
+        rt::RndGen rng = rt::RndGen::init(seed);
+        const rt::Hittable world = rt::Random_Scene(half_size, rng);
+        if (world.objects.size() > cap) return RT_E_CAP;
+        if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
+        soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
+        return (int)world.objects.size();
+    });
 }
 
 int rt_two_sphere_scene(uint32_t cap, float *cx, float *cy, float *cz, float *radius, uint32_t *kind, float *r,
                         float *g, float *b, float *param)
 {
-    const rt::Hittable world = rt::Two_Sphere_Scene();
-    if (world.objects.size() > cap) return RT_E_CAP;
-    if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
-    soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
-    return (int)world.objects.size();
+    return guarded([&]() -> int {
+        const rt::Hittable world = rt::Two_Sphere_Scene();
+        if (world.objects.size() > cap) return RT_E_CAP;
+        if (!cx || !cy || !cz || !radius || !kind || !r || !g || !b || !param) return RT_E_ARG;
+        soa_out(world.objects, cx, cy, cz, radius, kind, r, g, b, param);
+        return (int)world.objects.size();
+    });
 }
 
 int rt_tessellate_spheres(const rt_spheres *sph, int slices, int stacks, uint32_t cap, float *v0, float *v1,
                           float *v2, uint32_t *material)
 {
-    if (!sph || !sph->cx || !sph->cy || !sph->cz || !sph->radius) return RT_E_ARG;
-    std::vector<rt::Sphere> objs(sph->n);
-    for (uint32_t k = 0; k < sph->n; ++k) {
-        objs[k].center = { sph->cx[k], sph->cy[k], sph->cz[k] };
-        objs[k].radius = sph->radius[k];
-    }
-    const std::vector<rt::Triangle> tris = rt::Tessellate_Spheres(objs, slices, stacks);
-    if (cap == 0) return (int)tris.size();
-    if (tris.size() > cap) return RT_E_CAP;
-    if (!v0 || !v1 || !v2 || !material) return RT_E_ARG;
-    for (size_t k = 0; k < tris.size(); ++k) {
-        v0[3 * k] = tris[k].v0.x; v0[3 * k + 1] = tris[k].v0.y; v0[3 * k + 2] = tris[k].v0.z;
-        v1[3 * k] = tris[k].v1.x; v1[3 * k + 1] = tris[k].v1.y; v1[3 * k + 2] = tris[k].v1.z;
-        v2[3 * k] = tris[k].v2.x; v2[3 * k + 1] = tris[k].v2.y; v2[3 * k + 2] = tris[k].v2.z;
-        material[k] = tris[k].material;
-    }
-    return (int)tris.size();
+    return guarded([&]() -> int {
+        if (!sph || !sph->cx || !sph->cy || !sph->cz || !sph->radius) return RT_E_ARG;
+        std::vector<rt::Sphere> objs(sph->n);
+        for (uint32_t k = 0; k < sph->n; ++k) {
+            objs[k].center = { sph->cx[k], sph->cy[k], sph->cz[k] };
+            objs[k].radius = sph->radius[k];
+        }
+        const std::vector<rt::Triangle> tris = rt::Tessellate_Spheres(objs, slices, stacks);
+        if (cap == 0) return (int)tris.size();
+        if (tris.size() > cap) return RT_E_CAP;
+        if (!v0 || !v1 || !v2 || !material) return RT_E_ARG;
+        for (size_t k = 0; k < tris.size(); ++k) {
+            v0[3 * k] = tris[k].v0.x; v0[3 * k + 1] = tris[k].v0.y; v0[3 * k + 2] = tris[k].v0.z;
+            v1[3 * k] = tris[k].v1.x; v1[3 * k + 1] = tris[k].v1.y; v1[3 * k + 2] = tris[k].v1.z;
+            v2[3 * k] = tris[k].v2.x; v2[3 * k + 1] = tris[k].v2.y; v2[3 * k + 2] = tris[k].v2.z;
+            material[k] = tris[k].material;
+        }
+        return (int)tris.size();
+    });
 }
 
 int rt_write_ppm(const char *fname, const uint8_t *rgb8, uint32_t nx, uint32_t ny)
 {
-    if (!fname || !rgb8) return RT_E_ARG;
-    return rt::img_io::write_ppm_image(fname, rgb8, nx, ny) ? RT_OK : RT_E_IO;
+    return guarded([&]() -> int {
+        if (!fname || !rgb8) return RT_E_ARG;
+        return rt::img_io::write_ppm_image(fname, rgb8, nx, ny) ? RT_OK : RT_E_IO;
+    });
 }
 
 int rt_selftest_cbrt_grid(rt_ctx *ctx, float *out, uint64_t *n_risky)
