@@ -349,7 +349,13 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             float kind_bits; std::memcpy(&kind_bits, &mats->kind[k], 4);
             aux.push_back(make_float4(have_sph ? sph->radius[k] : 0.0f, kind_bits, mats->param[k],
                                       have_sph ? recip_for_div(sph->radius[k]) : 0.0f));
-            alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], 0.0f));
+            // two records per material: {r, g, b, schlick r0^2}, {1/index, 0, 0, 0}.  The two dielectric constants
+            // (raytracer.zig:464-466, :482) are the same IEEE operations the scatter code would do per hit.
+            const float idx = mats->param[k];
+            float r0 = (1.0f - idx) / (1.0f + idx);
+            r0 = r0 * r0;
+            alb.push_back(make_float4(mats->r[k], mats->g[k], mats->b[k], r0));
+            alb.push_back(make_float4(1.0f / idx, 0.0f, 0.0f, 0.0f));
         }
         if (have_sph) {
             for (uint32_t k = 0; k < sph->n; ++k) {

@@ -64,6 +64,7 @@ struct Surface {          // HitRecord (raytracer.zig:31-36) with the material f
     uint32_t kind;
     float    param;
     f3       albedo;
+    float    inv_param, r0sq;   // dielectric: 1/index and schlick's r0*r0, made once at upload (same IEEE operations)
 };
 
 // trace's per-sample prologue: raytracer.zig:537-539 and camera.zig:16/:39.  r = Philox block 0 of the sample.
@@ -125,9 +126,10 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
     } else {                                                       // Dielectric.scatter, :469-499
         const float param = S.param;
         const float ddn = dot(L.d, n);
-        f3 on; float ni_over_nt, cosine;
-        if (ddn > 0) { on = -n; ni_over_nt = param; cosine = (param * ddn) / len_d; }
-        else { on = n; ni_over_nt = 1.0f / param; cosine = (-ddn) / len_d; }
+        f3 on; float ni_over_nt, cos_num;
+        if (ddn > 0) { on = -n; ni_over_nt = param; cos_num = param * ddn; }
+        else { on = n; ni_over_nt = S.inv_param; cos_num = -ddn; }      // 1.0 / index, :482
+        const float cosine = cos_num / len_d;                              // one divide for both branches, :479/:487
         const float dt = dot(unit, on);                            // refract, :453-463
         const float disc = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
         float reflect_prob = 1.0f;
@@ -136,8 +138,7 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
             const float sq = sqrtf(disc);
             const f3 w = unit - dt * on;                           // uv - n*splat(dt)
             refracted = mk(ni_over_nt * w.x - on.x * sq, ni_over_nt * w.y - on.y * sq, ni_over_nt * w.z - on.z * sq);
-            float r0 = (1.0f - param) / (1.0f + param);            // schlick, :464-468
-            r0 = r0 * r0;
+            const float r0 = S.r0sq;                               // schlick, :464-468: ((1 - index) / (1 + index))^2
             reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
         }
         dir = (u32_to_unit_float(r[0]) < reflect_prob) ? reflected : refracted;   // :492-496
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     for (;;) {
         // resolve the rays of the previous iteration and give every lane its next ray
         shade_and_spawn<HIST, true>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
-            const float4 g = geom[prim], ax = aux[prim], al = albedo[prim];
+            const float4 g = geom[prim], ax = aux[prim], al = albedo[2u * prim], al2 = albedo[2u * prim + 1u];
             S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax);
-            S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
+            S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z); S.r0sq = al.w; S.inv_param = al2.x;
         });
         if (__ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
 
@@ -634,8 +635,8 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                         mat = prim;
                         S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), aux[mat]);
                     }
-                    const float4 ax = aux[mat], al = albedo[mat];
-                    S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z);
+                    const float4 ax = aux[mat], al = albedo[2u * mat], al2 = albedo[2u * mat + 1u];
+                    S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z); S.r0sq = al.w; S.inv_param = al2.x;
                 });
                 if (has_ray) {                        // start the new ray at the root
                     a = dot(L.d, L.d);
