@@ -209,11 +209,11 @@ __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ void box2_hit_fma(float4 X, float4 Y, float4 Z, f3 inv, f3 noi, float t_lo, float t_hi,
+struct RaySplat { v2f ix, iy, iz, nx, ny, nz; };     // {inv.x, inv.x} ... {noi.z, noi.z}: the packed FMAs' ray operands
+__device__ __forceinline__ void box2_hit_fma(float4 X, float4 Y, float4 Z, const RaySplat &R, float t_lo, float t_hi,
                                              bool &h0, bool &h1, float &tn0, float &tn1)
 {
-    const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
-    const v2f nx = { noi.x, noi.x }, ny = { noi.y, noi.y }, nz = { noi.z, noi.z };
+    const v2f ix = R.ix, iy = R.iy, iz = R.iz, nx = R.nx, ny = R.ny, nz = R.nz;
     const v2f x0 = __builtin_elementwise_fma((v2f){ X.x, X.y }, ix, nx), x1 = __builtin_elementwise_fma((v2f){ X.z, X.w }, ix, nx);
     const v2f y0 = __builtin_elementwise_fma((v2f){ Y.x, Y.y }, iy, ny), y1 = __builtin_elementwise_fma((v2f){ Y.z, Y.w }, iy, ny);
     const v2f z0 = __builtin_elementwise_fma((v2f){ Z.x, Z.y }, iz, nz), z1 = __builtin_elementwise_fma((v2f){ Z.z, Z.w }, iz, nz);
@@ -588,6 +588,12 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
     float best_t = T_MAX, a = 1.0f;
     f3 inv = mk(1, 1, 1), noi = mk(0, 0, 0);
+    // LDSN: the same six values as register pairs, made once per ray.  The empty asm keeps the compiler from
+    // re-splatting them (8 v_mov) and re-copying t_min (1 v_mov) on every traversal step.
+    RaySplat RS;
+    RS.ix = RS.iy = RS.iz = (v2f){ 1.0f, 1.0f }; RS.nx = RS.ny = RS.nz = (v2f){ 0.0f, 0.0f };
+    float t_min_v = P.t_min;
+    asm volatile("" : "+v"(t_min_v));
 
     // HIST builds also count how well the wave is filled in each phase (profiling aid; lane 0 of a wave
     // counts wave-level events, every lane its own)
@@ -646,6 +652,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     if (fabsf(dd.z) < 1e-30f) dd.z = copysignf(1e-30f, dd.z);
                     inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
                     noi = mk(-(L.o.x * inv.x), -(L.o.y * inv.y), -(L.o.z * inv.z));
+                    if (LDSN) {
+                        RS.ix = (v2f){ inv.x, inv.x }; RS.iy = (v2f){ inv.y, inv.y }; RS.iz = (v2f){ inv.z, inv.z };
+                        RS.nx = (v2f){ noi.x, noi.x }; RS.ny = (v2f){ noi.y, noi.y }; RS.nz = (v2f){ noi.z, noi.z };
+                        asm volatile("" : "+v"(RS.ix), "+v"(RS.iy), "+v"(RS.iz), "+v"(RS.nx), "+v"(RS.ny), "+v"(RS.nz));
+                    }
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                 }
             }
@@ -663,7 +674,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 float tn0, tn1;
                 bool h0, h1;
                 if (LDSN) {
-                    box2_hit_fma(q0, q1, q2, inv, noi, P.t_min, best_t, h0, h1, tn0, tn1);
+                    box2_hit_fma(q0, q1, q2, RS, t_min_v, best_t, h0, h1, tn0, tn1);
                 } else {
                     h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
                     h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
