@@ -202,27 +202,33 @@ __device__ __forceinline__ bool box_hit_fma(f3 lo, f3 hi, f3 inv, f3 noi, float 
     return n <= f;
 }
 
-// Both child boxes of a node at once with packed FMAs (v_pk_fma_f32: two FMAs per issue slot).  X/Y/Z hold one
-// axis each as {lo0, lo1, hi0, hi1} -- the layout the LDS-staged nodes use.
+// Both child boxes of a node at once (LDS-staged scenes).  Two things make this cheaper than two box_hit_fma:
+// packed FMAs (v_pk_fma_f32: the two boxes' planes of one axis in one issue slot), and no min/max per axis: the
+// node stores every axis as {hi0, hi1, lo0, lo1, hi0, hi1}, and a lane reads its 16 bytes at +8 when its ray runs
+// up that axis and at +0 when it runs down, so the first pair it gets is always the NEAR planes of the two
+// boxes and the second the FAR planes (the sign of inv decides which of lo/hi is nearer, and rounding is
+// monotonic, so the selected values are exactly the min and max the generic test would compute).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-struct RaySplat { v2f ix, iy, iz, nx, ny, nz; };     // {inv.x, inv.x} ... {noi.z, noi.z}: the packed FMAs' ray operands
-__device__ __forceinline__ void box2_hit_fma(float4 X, float4 Y, float4 Z, const RaySplat &R, float t_lo, float t_hi,
+struct RaySplat {
+    v2f      ix, iy, iz, nx, ny, nz;   // {inv.x, inv.x} ... {noi.z, noi.z}: the packed FMAs' ray operands
+    uint32_t ox, oy, oz;               // byte offset of the lane's {near pair, far pair} of each axis inside a node
+};
+constexpr uint32_t LDS_AXIS_BYTES = 24, LDS_REFS_OFFSET = 72;
+__device__ __forceinline__ void box2_hit_fma(const char *node, const RaySplat &R, float t_lo, float t_hi,
                                              bool &h0, bool &h1, float &tn0, float &tn1)
 {
-    const v2f ix = R.ix, iy = R.iy, iz = R.iz, nx = R.nx, ny = R.ny, nz = R.nz;
-    const v2f x0 = __builtin_elementwise_fma((v2f){ X.x, X.y }, ix, nx), x1 = __builtin_elementwise_fma((v2f){ X.z, X.w }, ix, nx);
-    const v2f y0 = __builtin_elementwise_fma((v2f){ Y.x, Y.y }, iy, ny), y1 = __builtin_elementwise_fma((v2f){ Y.z, Y.w }, iy, ny);
-    const v2f z0 = __builtin_elementwise_fma((v2f){ Z.x, Z.y }, iz, nz), z1 = __builtin_elementwise_fma((v2f){ Z.z, Z.w }, iz, nz);
+    const v2f *px = (const v2f *)(node + R.ox), *py = (const v2f *)(node + R.oy), *pz = (const v2f *)(node + R.oz);
+    const v2f xn = __builtin_elementwise_fma(px[0], R.ix, R.nx), xf = __builtin_elementwise_fma(px[1], R.ix, R.nx);
+    const v2f yn = __builtin_elementwise_fma(py[0], R.iy, R.ny), yf = __builtin_elementwise_fma(py[1], R.iy, R.ny);
+    const v2f zn = __builtin_elementwise_fma(pz[0], R.iz, R.nz), zf = __builtin_elementwise_fma(pz[1], R.iz, R.nz);
     // plain hardware min/max: fminf/fmaxf would first re-canonicalise the halves taken out of the packed results
     // (one extra v_max per operand); every input here is an FMA result or a finite bound, so there is no sNaN to quiet
-    const float n0 = hw_max3(hw_min(x0.x, x1.x), hw_min(y0.x, y1.x), hw_max(hw_min(z0.x, z1.x), t_lo));
-    const float f0 = hw_min3(hw_max(x0.x, x1.x), hw_max(y0.x, y1.x), hw_min(hw_max(z0.x, z1.x), t_hi));
-    const float n1 = hw_max3(hw_min(x0.y, x1.y), hw_min(y0.y, y1.y), hw_max(hw_min(z0.y, z1.y), t_lo));
-    const float f1 = hw_min3(hw_max(x0.y, x1.y), hw_max(y0.y, y1.y), hw_min(hw_max(z0.y, z1.y), t_hi));
+    const float n0 = hw_max3(xn.x, yn.x, hw_max(zn.x, t_lo)), f0 = hw_min3(xf.x, yf.x, hw_min(zf.x, t_hi));
+    const float n1 = hw_max3(xn.y, yn.y, hw_max(zn.y, t_lo)), f1 = hw_min3(xf.y, yf.y, hw_min(zf.y, t_hi));
     tn0 = n0; tn1 = n1;
     h0 = n0 <= f0; h1 = n1 <= f1;
 }
@@ -554,20 +560,22 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
-        // one thread per node: the two child boxes are interleaved per axis, {lo0, lo1, hi0, hi1}, for the packed
-        // slab test; inner-node child refs become BYTE offsets into s_scene (one multiply per step saved; they
-        // still fit the 16-bit stack entries because the staged scene is at most 40 KB)
+        // one thread per node, 80 bytes each: per axis {hi0, hi1, lo0, lo1, hi0, hi1} (see box2_hit_fma), then the
+        // two child refs; inner-node refs become BYTE offsets into s_scene (no multiply per step; they still fit
+        // the 16-bit stack entries because the staged scene is at most 40 KB)
         for (uint32_t k = threadIdx.x; k < n_nodes; k += NT) {
-            const float4 q0 = bvh[4u * k], q1 = bvh[4u * k + 1u], q2 = bvh[4u * k + 2u];
-            float4 q3 = bvh[4u * k + 3u];
-            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            if (!(c0 & LEAF_BIT)) q3.x = __uint_as_float(c0 * (uint32_t)(LDS_NODE_STRIDE * 16));
-            if (!(c1 & LEAF_BIT)) q3.y = __uint_as_float(c1 * (uint32_t)(LDS_NODE_STRIDE * 16));
-            float4 *dst = s_scene + k * LDS_NODE_STRIDE;
-            dst[0] = make_float4(q0.x, q1.z, q0.w, q2.y);     // x: lo0, lo1, hi0, hi1
-            dst[1] = make_float4(q0.y, q1.w, q1.x, q2.z);     // y
-            dst[2] = make_float4(q0.z, q2.x, q1.y, q2.w);     // z
-            dst[3] = q3;
+            const float4 q0 = bvh[4u * k], q1 = bvh[4u * k + 1u], q2 = bvh[4u * k + 2u], q3 = bvh[4u * k + 3u];
+            const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
+            const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
+            float *dst = (float *)(s_scene + k * LDS_NODE_STRIDE);
+            for (int ax = 0; ax < 3; ++ax) {
+                float *d = dst + 6 * ax;
+                d[0] = hi0[ax]; d[1] = hi1[ax]; d[2] = lo0[ax]; d[3] = lo1[ax]; d[4] = hi0[ax]; d[5] = hi1[ax];
+            }
+            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (!(c0 & LEAF_BIT)) c0 *= (uint32_t)(LDS_NODE_STRIDE * 16);
+            if (!(c1 & LEAF_BIT)) c1 *= (uint32_t)(LDS_NODE_STRIDE * 16);
+            dst[18] = __uint_as_float(c0); dst[19] = __uint_as_float(c1);
         }
         if (KIND == KIND_BVH_SPHERES)
             for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     // re-splatting them (8 v_mov) and re-copying t_min (1 v_mov) on every traversal step.
     RaySplat RS;
     RS.ix = RS.iy = RS.iz = (v2f){ 1.0f, 1.0f }; RS.nx = RS.ny = RS.nz = (v2f){ 0.0f, 0.0f };
+    RS.ox = 8u; RS.oy = LDS_AXIS_BYTES + 8u; RS.oz = 2u * LDS_AXIS_BYTES + 8u;
     float t_min_v = P.t_min;
     asm volatile("" : "+v"(t_min_v));
 
@@ -655,6 +664,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     if (LDSN) {
                         RS.ix = (v2f){ inv.x, inv.x }; RS.iy = (v2f){ inv.y, inv.y }; RS.iz = (v2f){ inv.z, inv.z };
                         RS.nx = (v2f){ noi.x, noi.x }; RS.ny = (v2f){ noi.y, noi.y }; RS.nz = (v2f){ noi.z, noi.z };
+                        // running up an axis (sign bit clear): near = lo, the pair at +8; running down: near = hi, at +0
+                        RS.ox = ((__float_as_uint(dd.x) >> 31) ^ 1u) << 3;
+                        RS.oy = LDS_AXIS_BYTES + (((__float_as_uint(dd.y) >> 31) ^ 1u) << 3);
+                        RS.oz = 2u * LDS_AXIS_BYTES + (((__float_as_uint(dd.z) >> 31) ^ 1u) << 3);
                         asm volatile("" : "+v"(RS.ix), "+v"(RS.iy), "+v"(RS.iz), "+v"(RS.nx), "+v"(RS.ny), "+v"(RS.nz));
                     }
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
@@ -669,17 +682,21 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if (HIST) c_wsteps += 1;
             if (node != DONE) {
                 if (HIST) c_lsteps += 1;
-                const float4 *nd = LDSN ? (const float4 *)((const char *)s_scene + node) : bvh + 4u * node;
-                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 float tn0, tn1;
                 bool h0, h1;
+                uint32_t c0, c1;
                 if (LDSN) {
-                    box2_hit_fma(q0, q1, q2, RS, t_min_v, best_t, h0, h1, tn0, tn1);
+                    const char *nd = (const char *)s_scene + node;
+                    box2_hit_fma(nd, RS, t_min_v, best_t, h0, h1, tn0, tn1);
+                    const uint2 refs = *(const uint2 *)(nd + LDS_REFS_OFFSET);
+                    c0 = refs.x; c1 = refs.y;
                 } else {
+                    const float4 *nd = bvh + 4u * node;
+                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                     h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
                     h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
+                    c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
                 }
-                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                 const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
                 if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
                 if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
