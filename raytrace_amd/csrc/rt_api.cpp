@@ -379,8 +379,23 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         if (const char *e = std::getenv("RT_HIP_BVH_DEPTH_CAP")) { const int v = std::atoi(e); if (v >= 8 && v <= 32) depth_cap = v; }
         const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
         if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
-        std::vector<float4> nodes(tree.nodes.size() * 4);
-        if (!nodes.empty()) std::memcpy(nodes.data(), tree.nodes.data(), nodes.size() * sizeof(float4));
+        // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)
+        if (tree.nodes.size() * (uint64_t)RT_NODE_BYTES >= 0x80000000ull) return RT_E_ARG;   // byte offsets keep bit 31 free
+        std::vector<float4> nodes(tree.nodes.size() * (RT_NODE_BYTES / 16));
+        for (size_t k = 0; k < tree.nodes.size(); ++k) {
+            const float *w = tree.nodes[k].w;
+            float *d = reinterpret_cast<float *>(nodes.data() + k * (RT_NODE_BYTES / 16));
+            for (int ax = 0; ax < 3; ++ax) {
+                const float lo0 = w[ax], hi0 = w[3 + ax], lo1 = w[6 + ax], hi1 = w[9 + ax];
+                float *a = d + 6 * ax;
+                a[0] = hi0; a[1] = hi1; a[2] = lo0; a[3] = lo1; a[4] = hi0; a[5] = hi1;
+            }
+            for (int c = 0; c < 2; ++c) {
+                uint32_t ref; std::memcpy(&ref, &w[12 + c], 4);
+                if (!(ref & rtbvh::LEAF_BIT)) ref *= (uint32_t)RT_NODE_BYTES;
+                std::memcpy(&d[18 + c], &ref, 4);
+            }
+        }
 
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

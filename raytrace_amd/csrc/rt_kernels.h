@@ -33,6 +33,12 @@ struct TraceParams {
 //   triangles: tri[3i+0] = { v0.xyz, bits(material) }, tri[3i+1] = { v1.xyz, 0 }, tri[3i+2] = { v2.xyz, 0 }
 //              aux/albedo are the material table (aux.x unused)
 //   bvh:       4 float4 per node (rt_bvh.hpp Node), root = node 0
+// Device BVH node, RT_NODE_BYTES = 80: per axis (x, y, z; 24 bytes each) the planes of the two child boxes as
+// {hi0, hi1, lo0, lo1, hi0, hi1} -- a lane reads 16 bytes at +8 (ray runs up the axis) or +0 (down) and gets
+// {near0, near1, far0, far1} without a min/max --, then the two child refs at byte 72: bit 31 set = primitive index,
+// else the BYTE offset of the child node.  Made from the host tree (rt_bvh.hpp) at upload, rt_api.cpp.
+constexpr int RT_NODE_BYTES = 80;
+
 struct DeviceScene {
     const float4 *geom = nullptr;
     const float4 *tri = nullptr;

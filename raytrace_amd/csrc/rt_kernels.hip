@@ -189,22 +189,11 @@ __device__ __forceinline__ void triangle_exact(f3 v0, f3 v1, f3 v2, uint32_t pri
     if ((t < T_MAX) && (t > t_min) && ((t < best_t) || (t == best_t && prim < best))) { best_t = t; best = prim; }
 }
 
-// slab test of one padded box in FMA form: plane distance = lo*inv - o*inv (noi = -(o*inv)).  Only
-// culls, so it may round differently from the CPU: the padding covers it (rt_bvh.hpp).
-__device__ __forceinline__ bool box_hit_fma(f3 lo, f3 hi, f3 inv, f3 noi, float t_lo, float t_hi, float &tn)
-{
-    const float x0 = __builtin_fmaf(lo.x, inv.x, noi.x), x1 = __builtin_fmaf(hi.x, inv.x, noi.x);
-    const float y0 = __builtin_fmaf(lo.y, inv.y, noi.y), y1 = __builtin_fmaf(hi.y, inv.y, noi.y);
-    const float z0 = __builtin_fmaf(lo.z, inv.z, noi.z), z1 = __builtin_fmaf(hi.z, inv.z, noi.z);
-    const float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
-    const float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_hi));
-    tn = n;
-    return n <= f;
-}
-
-// Both child boxes of a node at once (LDS-staged scenes).  Two things make this cheaper than two box_hit_fma:
+// Slab test of both (padded) child boxes of a node in FMA form: plane distance = plane*inv - o*inv (noi = -(o*inv)).
+// It only culls, so it may round differently from the CPU: the padding covers it (rt_bvh.hpp).  Two things make it
+// cheap:
 // packed FMAs (v_pk_fma_f32: the two boxes' planes of one axis in one issue slot), and no min/max per axis: the
-// node stores every axis as {hi0, hi1, lo0, lo1, hi0, hi1}, and a lane reads its 16 bytes at +8 when its ray runs
+// device node (80 bytes, rt_kernels.h) stores every axis as {hi0, hi1, lo0, lo1, hi0, hi1}, and a lane reads its 16 bytes at +8 when its ray runs
 // up that axis and at +0 when it runs down, so the first pair it gets is always the NEAR planes of the two
 // boxes and the second the FAR planes (the sign of inv decides which of lo/hi is nearer, and rounding is
 // monotonic, so the selected values are exactly the min and max the generic test would compute).
@@ -217,14 +206,16 @@ struct RaySplat {
     v2f      ix, iy, iz, nx, ny, nz;   // {inv.x, inv.x} ... {noi.z, noi.z}: the packed FMAs' ray operands
     uint32_t ox, oy, oz;               // byte offset of the lane's {near pair, far pair} of each axis inside a node
 };
-constexpr uint32_t LDS_AXIS_BYTES = 24, LDS_REFS_OFFSET = 72;
+constexpr uint32_t NODE_AXIS_BYTES = 24, NODE_REFS_OFFSET = 72;   // layout of RT_NODE_BYTES = 80 (rt_kernels.h)
+struct __attribute__((aligned(8))) PlanePairs { v2f near_, far_; };   // 16 bytes at 8-byte alignment: one ds_read2_b64 / global_load_dwordx4
 __device__ __forceinline__ void box2_hit_fma(const char *node, const RaySplat &R, float t_lo, float t_hi,
                                              bool &h0, bool &h1, float &tn0, float &tn1)
 {
-    const v2f *px = (const v2f *)(node + R.ox), *py = (const v2f *)(node + R.oy), *pz = (const v2f *)(node + R.oz);
-    const v2f xn = __builtin_elementwise_fma(px[0], R.ix, R.nx), xf = __builtin_elementwise_fma(px[1], R.ix, R.nx);
-    const v2f yn = __builtin_elementwise_fma(py[0], R.iy, R.ny), yf = __builtin_elementwise_fma(py[1], R.iy, R.ny);
-    const v2f zn = __builtin_elementwise_fma(pz[0], R.iz, R.nz), zf = __builtin_elementwise_fma(pz[1], R.iz, R.nz);
+    const PlanePairs px = *(const PlanePairs *)(node + R.ox), py = *(const PlanePairs *)(node + R.oy),
+                     pz = *(const PlanePairs *)(node + R.oz);
+    const v2f xn = __builtin_elementwise_fma(px.near_, R.ix, R.nx), xf = __builtin_elementwise_fma(px.far_, R.ix, R.nx);
+    const v2f yn = __builtin_elementwise_fma(py.near_, R.iy, R.ny), yf = __builtin_elementwise_fma(py.far_, R.iy, R.ny);
+    const v2f zn = __builtin_elementwise_fma(pz.near_, R.iz, R.nz), zf = __builtin_elementwise_fma(pz.far_, R.iz, R.nz);
     // plain hardware min/max: fminf/fmaxf would first re-canonicalise the halves taken out of the packed results
     // (one extra v_max per operand); every input here is an FMA result or a finite bound, so there is no sNaN to quiet
     const float n0 = hw_max3(xn.x, yn.x, hw_max(zn.x, t_lo)), f0 = hw_min3(xf.x, yf.x, hw_min(zf.x, t_hi));
@@ -539,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
 // over all bank quads instead of 4) and the sphere records -- and stack/queue entries shrink to 16 bits.
 // LDSN = false (large scenes, e.g. 285k triangles): nodes and primitives are read from global memory
 // through L1/L2.
-constexpr int LDS_NODE_STRIDE = 5;                    // float4 per node in LDS (4 used + 1 pad)
+constexpr int LDS_NODE_STRIDE = RT_NODE_BYTES / 16;    // float4 per node
 
 template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT>
 __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
@@ -560,23 +551,9 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
-        // one thread per node, 80 bytes each: per axis {hi0, hi1, lo0, lo1, hi0, hi1} (see box2_hit_fma), then the
-        // two child refs; inner-node refs become BYTE offsets into s_scene (no multiply per step; they still fit
-        // the 16-bit stack entries because the staged scene is at most 40 KB)
-        for (uint32_t k = threadIdx.x; k < n_nodes; k += NT) {
-            const float4 q0 = bvh[4u * k], q1 = bvh[4u * k + 1u], q2 = bvh[4u * k + 2u], q3 = bvh[4u * k + 3u];
-            const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
-            const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
-            float *dst = (float *)(s_scene + k * LDS_NODE_STRIDE);
-            for (int ax = 0; ax < 3; ++ax) {
-                float *d = dst + 6 * ax;
-                d[0] = hi0[ax]; d[1] = hi1[ax]; d[2] = lo0[ax]; d[3] = lo1[ax]; d[4] = hi0[ax]; d[5] = hi1[ax];
-            }
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            if (!(c0 & LEAF_BIT)) c0 *= (uint32_t)(LDS_NODE_STRIDE * 16);
-            if (!(c1 & LEAF_BIT)) c1 *= (uint32_t)(LDS_NODE_STRIDE * 16);
-            dst[18] = __uint_as_float(c0); dst[19] = __uint_as_float(c1);
-        }
+        // the device nodes are already in traversal format (80 bytes, child refs = byte offsets): straight copy.
+        // The 80-byte stride also spreads 16 lanes' reads of random nodes over all bank quads.
+        for (uint32_t k = threadIdx.x; k < n_nodes * LDS_NODE_STRIDE; k += NT) s_scene[k] = bvh[k];
         if (KIND == KIND_BVH_SPHERES)
             for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
                 s_scene[n_nodes * LDS_NODE_STRIDE + k] = geom[k];
@@ -595,12 +572,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     // traversal state of the lane's current ray
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
     float best_t = T_MAX, a = 1.0f;
-    f3 inv = mk(1, 1, 1), noi = mk(0, 0, 0);
-    // LDSN: the same six values as register pairs, made once per ray.  The empty asm keeps the compiler from
+    // the same six values as register pairs, made once per ray.  The empty asm keeps the compiler from
     // re-splatting them (8 v_mov) and re-copying t_min (1 v_mov) on every traversal step.
     RaySplat RS;
     RS.ix = RS.iy = RS.iz = (v2f){ 1.0f, 1.0f }; RS.nx = RS.ny = RS.nz = (v2f){ 0.0f, 0.0f };
-    RS.ox = 8u; RS.oy = LDS_AXIS_BYTES + 8u; RS.oz = 2u * LDS_AXIS_BYTES + 8u;
+    RS.ox = 8u; RS.oy = NODE_AXIS_BYTES + 8u; RS.oz = 2u * NODE_AXIS_BYTES + 8u;
     float t_min_v = P.t_min;
     asm volatile("" : "+v"(t_min_v));
 
@@ -659,15 +635,15 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     if (fabsf(dd.x) < 1e-30f) dd.x = copysignf(1e-30f, dd.x);
                     if (fabsf(dd.y) < 1e-30f) dd.y = copysignf(1e-30f, dd.y);
                     if (fabsf(dd.z) < 1e-30f) dd.z = copysignf(1e-30f, dd.z);
-                    inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
-                    noi = mk(-(L.o.x * inv.x), -(L.o.y * inv.y), -(L.o.z * inv.z));
-                    if (LDSN) {
+                    const f3 inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
+                    const f3 noi = mk(-(L.o.x * inv.x), -(L.o.y * inv.y), -(L.o.z * inv.z));
+                    {
                         RS.ix = (v2f){ inv.x, inv.x }; RS.iy = (v2f){ inv.y, inv.y }; RS.iz = (v2f){ inv.z, inv.z };
                         RS.nx = (v2f){ noi.x, noi.x }; RS.ny = (v2f){ noi.y, noi.y }; RS.nz = (v2f){ noi.z, noi.z };
                         // running up an axis (sign bit clear): near = lo, the pair at +8; running down: near = hi, at +0
                         RS.ox = ((__float_as_uint(dd.x) >> 31) ^ 1u) << 3;
-                        RS.oy = LDS_AXIS_BYTES + (((__float_as_uint(dd.y) >> 31) ^ 1u) << 3);
-                        RS.oz = 2u * LDS_AXIS_BYTES + (((__float_as_uint(dd.z) >> 31) ^ 1u) << 3);
+                        RS.oy = NODE_AXIS_BYTES + (((__float_as_uint(dd.y) >> 31) ^ 1u) << 3);
+                        RS.oz = 2u * NODE_AXIS_BYTES + (((__float_as_uint(dd.z) >> 31) ^ 1u) << 3);
                         asm volatile("" : "+v"(RS.ix), "+v"(RS.iy), "+v"(RS.iz), "+v"(RS.nx), "+v"(RS.ny), "+v"(RS.nz));
                     }
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
@@ -684,19 +660,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 if (HIST) c_lsteps += 1;
                 float tn0, tn1;
                 bool h0, h1;
-                uint32_t c0, c1;
-                if (LDSN) {
-                    const char *nd = (const char *)s_scene + node;
-                    box2_hit_fma(nd, RS, t_min_v, best_t, h0, h1, tn0, tn1);
-                    const uint2 refs = *(const uint2 *)(nd + LDS_REFS_OFFSET);
-                    c0 = refs.x; c1 = refs.y;
-                } else {
-                    const float4 *nd = bvh + 4u * node;
-                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-                    h0 = box_hit_fma(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), inv, noi, P.t_min, best_t, tn0);
-                    h1 = box_hit_fma(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), inv, noi, P.t_min, best_t, tn1);
-                    c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
-                }
+                const char *nd = (LDSN ? (const char *)s_scene : (const char *)bvh) + node;   // node = byte offset
+                box2_hit_fma(nd, RS, t_min_v, best_t, h0, h1, tn0, tn1);
+                const uint2 refs = *(const uint2 *)(nd + NODE_REFS_OFFSET);
+                const uint32_t c0 = refs.x, c1 = refs.y;
                 const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
                 if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
                 if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
