@@ -499,6 +499,19 @@ def test_error_codes(gpu_ctx):
         gpu_ctx.upload_scene(R.Two_Sphere_Scene(), triangles=tri, materials=R.Two_Sphere_Scene())
 
 
+def test_randomised_scenes_cameras_and_configs():
+    """tools/gpu_fuzz.py: 300 random cases (sphere scenes up to 700 spheres incl. hollow glass and coincident
+    centres, tessellated meshes under several depth caps, cameras, image sizes down to 1x1, sample sub-ranges,
+    chunk sizes, depth caps 0..40, t_min 0) -- ray counts exact, linear mean within 1e-3 in every one.  Runs in its
+    own process because it drives the library's environment knobs."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "300", "7"], capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "fuzz: 300 cases ok" in out.stdout
+
+
 # ---- device-resident entry points (what bench.py and the multi-GPU driver use) ----------------------------
 def test_render_device_and_tonemap_device(gpu_ctx):
     import torch
