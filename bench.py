@@ -171,7 +171,7 @@ def main():
                             "lane_utilisation": d.get("valu_lane_utilisation"),
                             "source": "profiles/latest_%s_pmc.json (SQ_THREAD_CYCLES_VALU, SQ_INSTS_VALU)" % args.workload}
         out = {
-            "metric": "Mrays/sec (all bounces) book scene 1080p 100spp; %FP32 VALU roofline",
+            "metric": "Mrays/sec (all bounces) book scene 1080p 100spp; %FP32 VALU roofline @1/8 GPU",   # BASELINE.json, verbatim
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
