@@ -153,9 +153,10 @@ def main():
         if world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 d = json.load(f).get("derived", {})
-            if "hbm_write_bytes" in d and "hbm_read_bytes_counter" in d:
-                traffic = d["hbm_read_bytes_counter"] + d["hbm_write_bytes"]
-                traffic_src = "profiles/latest_%s_pmc.json (FETCH_SIZE*1KiB uncorrected + WRITE_SIZE*1KiB)" % args.workload
+            if "hbm_write_bytes" in d and "hbm_read_bytes_x2_correction" in d:
+                # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) counts half the bytes on gfx950 -> doubled; WRITE_SIZE as is
+                traffic = d["hbm_read_bytes_x2_correction"] + d["hbm_write_bytes"]
+                traffic_src = "profiles/latest_%s_pmc.json (2 x FETCH_SIZE KiB + WRITE_SIZE KiB, separate --pmc passes)" % args.workload
         achieved = rays_per_step[0] * fpr / (k_ms * 1e-3) / 1e12
         # executed (hardware-counted) VALU work of the same launch, from the same committed PMC pass: active lanes
         # summed over all VALU instructions, against the chip's lane-issue peak (256 CU x 128 lanes x 2.4 GHz)
