@@ -108,6 +108,7 @@ def main():
     strong = args.workload in STRONG
     spp_total = spp if strong else spp * world      # weak: every GPU adds its own `spp` samples to the image
     kernel_ms = []
+    reduce_ms = []
     rays_per_step = [0]
 
     def step(record):
@@ -115,6 +116,7 @@ def main():
         res = render_sample_sharded(renderer, spp_total, dist, accum)
         if record:
             kernel_ms.append(res.kernel_ms)
+            reduce_ms.append(res.reduce_ms)
             rays_per_step[0] = res.rays
 
     def fence():
@@ -178,7 +180,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_DESC[args.workload], "n_spheres": len(spheres), "nx": nx, "ny": ny,
                        "spp_per_gpu": spp_total / world, "spp_total": spp_total, "max_depth": depth, "seed": 1,
-                       "rays_per_step": rays_all, "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
+                       "rays_per_step": rays_all, "reduce_ms_rank0": float(np.mean(reduce_ms)) if world > 1 else 0.0,
+                       "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "executed": executed,

@@ -44,6 +44,7 @@ class ShardedResult:
     rgb8: object            # rank 0: [P*3] u8; other ranks: None
     rays: int               # this rank's rays
     kernel_ms: float
+    reduce_ms: float = 0.0  # wall time of the exchange step on this rank (waiting for the slowest rank included)
 
 
 class HipRangeRenderer:
@@ -95,12 +96,18 @@ def render_sample_sharded(renderer, spp_total, dist=None, accum=None):
         accum.zero_()
     begin, end = shard_spp(spp_total, world, rank)
     rays, ms = renderer.render_range(accum, begin, end, spp_total)
+    reduce_ms = 0.0
     if world > 1:
+        import time
+        t0 = time.perf_counter()
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's one exchange step
+        if accum.is_cuda:
+            torch.cuda.synchronize()
+        reduce_ms = (time.perf_counter() - t0) * 1e3
     if rank == 0:
         mean, rgb8 = renderer.tonemap(accum, spp_total)
-        return ShardedResult(mean, rgb8, rays, ms)
-    return ShardedResult(None, None, rays, ms)
+        return ShardedResult(mean, rgb8, rays, ms, reduce_ms)
+    return ShardedResult(None, None, rays, ms, reduce_ms)
 
 
 def quantise(mean):
