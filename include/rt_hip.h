@@ -116,6 +116,11 @@ int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles,
  * out = { wave traversal steps, lane traversal steps, wave exact-test iterations, lane exact-test
  * iterations, wave shading passes, lanes shaded } -- lane/(64*wave) is the fill of each phase. */
 int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6]);
+/* Profiling aid, no reference counterpart: after a render with RT_FLAG_DEPTH_HISTOGRAM, pairs {wave-level
+ * executions, lanes} for the blocks of the shading pass, in this order: surface fetch, normalize(direction), sky,
+ * work-item dequeue, Philox, camera ray, random_in_unit_sphere, cbrt fallback, lambertian, metal, dielectric,
+ * hit-normal IEEE fallback.  Returns the number of values written (24) or RT_E_CAP. */
+int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out);
 /* Name of the trace kernel the last render launched (for profiles). */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 

@@ -250,6 +250,17 @@ class Context:
                 "wave_exact_iters": wf, "lane_exact_iters": lf, "exact_fill": lf / max(1, 64 * wf),
                 "wave_shade_passes": wsh, "lanes_shaded": lsh, "shade_fill": lsh / max(1, 64 * wsh)}
 
+    BLOCK_NAMES = ("surface fetch", "normalize(direction)", "sky", "work-item dequeue", "philox", "camera ray",
+                   "random_in_unit_sphere", "cbrt fallback", "lambertian", "metal", "dielectric", "normal IEEE fallback")
+
+    def block_counts(self):
+        """Blocks of the shading pass in the last RT_FLAG_DEPTH_HISTOGRAM render: name -> (wave executions, lanes)."""
+        out = (C.c_uint64 * 64)()
+        n = self._L.rt_debug_block_counts(self._h, 64, out)
+        if n < 0:
+            raise RtError(n, "rt_debug_block_counts", 0)
+        return {self.BLOCK_NAMES[k]: (int(out[2 * k]), int(out[2 * k + 1])) for k in range(n // 2)}
+
     def last_kernel_name(self):
         return self._L.rt_last_kernel_name(self._h).decode()
 

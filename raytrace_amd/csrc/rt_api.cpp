@@ -30,6 +30,7 @@ struct rt_ctx {
     int          bvh_depth = 0;
     TraceKernel  last_kernel = RT_K_BRUTE_SPHERES;
     uint64_t     fill_counters[6] = { 0, 0, 0, 0, 0, 0 };
+    uint64_t     block_counters[2 * RT_PROF_BLOCKS] = { 0 };
     // per-render scratch owned by the ctx
     uint32_t    *d_queue = nullptr;            // work-queue head
     unsigned long long *d_stats = nullptr;     // RT_STATS_WORDS
@@ -223,6 +224,7 @@ int read_stats(rt_ctx *ctx, hipStream_t stream, rt_stats *stats)
     stats->rays = h[0]; stats->primary_rays = h[1]; stats->kernel_ms = ms;
     for (int k = 0; k < 20; ++k) stats->rays_by_depth[k] = h[2 + k];
     for (int k = 0; k < 6; ++k) ctx->fill_counters[k] = h[22 + k];
+    for (int k = 0; k < 2 * RT_PROF_BLOCKS; ++k) ctx->block_counters[k] = h[28 + k];
     return RT_OK;
 }
 
@@ -433,6 +435,14 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6])
     if (!ctx || !out) return RT_E_ARG;
     for (int k = 0; k < 6; ++k) out[k] = ctx->fill_counters[k];
     return RT_OK;
+}
+
+int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out)
+{
+    if (!ctx || !out) return RT_E_ARG;
+    if (cap < 2 * RT_PROF_BLOCKS) return RT_E_CAP;
+    for (int k = 0; k < 2 * RT_PROF_BLOCKS; ++k) out[k] = ctx->block_counters[k];
+    return 2 * RT_PROF_BLOCKS;
 }
 
 const char *rt_last_kernel_name(const rt_ctx *ctx)

@@ -55,7 +55,11 @@ enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANG
 // stats buffer layout (unsigned long long[]): [0] rays, [1] primary rays, [2..21] rays by depth,
 // [22..27] BVH wave-fill counters of histogram builds: wave/lane traversal steps, wave/lane exact-test
 // iterations, wave/lane shading passes
-enum { RT_STATS_WORDS = 28 };
+// Profiling builds (RT_FLAG_DEPTH_HISTOGRAM) also count how often the blocks of the shading pass run (wave level) and
+// with how many lanes; stats[28 + 2*b] = wave-level executions of block b, stats[29 + 2*b] = lanes that ran it.
+enum { RT_PB_SURFACE, RT_PB_UNIT, RT_PB_SKY, RT_PB_DEQUEUE, RT_PB_PHILOX, RT_PB_CAMERA, RT_PB_RIUS, RT_PB_CBRT_SLOW,
+       RT_PB_LAMBERTIAN, RT_PB_METAL, RT_PB_DIELECTRIC, RT_PB_NORMAL_SLOW, RT_PROF_BLOCKS };
+enum { RT_HIST_WORDS = 20, RT_STATS_WORDS = 28 + 2 * RT_PROF_BLOCKS };
 
 hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const DeviceScene &s, float *accum_sum,
                            float *partial, uint32_t *raycount, uint32_t *queue, unsigned long long *stats,

@@ -43,6 +43,17 @@ constexpr int      BLOCK = 256;
 
 enum : uint32_t { K_LAMBERTIAN = 0, K_METAL = 1, K_DIELECTRIC = 2 };
 
+// profiling builds: count one wave-level execution and the active lanes of a block (LDS counters behind the depth
+// histogram); `prof` is null in production builds and the call folds away
+__device__ __forceinline__ void prof_block(uint32_t *prof, int block)
+{
+    if (prof) {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&prof[2 * block], 1u);
+        atomicAdd(&prof[2 * block + 1], 1u);
+    }
+}
+
 struct Lane {
     f3       o, d;        // current ray (direction never normalised, as in the reference)
     f3       thr;         // product of attenuations so far
@@ -86,19 +97,19 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Lane &L, const 
 // kind, param, RN(1/radius) or NaN}: with the host-made reciprocal each quotient is a multiply and two FMAs
 // (div_recip) instead of the ~11-instruction IEEE divide.  |pc| ~ |radius| at a hit point, so nothing overflows;
 // zero or tiny components (< 2^-100) and spheres without a usable reciprocal take the IEEE divide, wave-wide.
-__device__ __forceinline__ f3 sphere_normal(f3 pc, float4 ax)
+__device__ __forceinline__ f3 sphere_normal(f3 pc, float4 ax, uint32_t *prof = nullptr)
 {
     f3 n = mk(div_recip(pc.x, ax.x, ax.w), div_recip(pc.y, ax.x, ax.w), div_recip(pc.z, ax.x, ax.w));
     const float m = fminf(fminf(__builtin_fabsf(pc.x), __builtin_fabsf(pc.y)), __builtin_fabsf(pc.z));
     const bool slow = !(m >= 0x1.0p-100f) || !(ax.w == ax.w);
-    if (__ballot(slow) != 0ull) n = pc / ax.x;
+    if (__ballot(slow) != 0ull) { prof_block(prof, RT_PB_NORMAL_SLOW); n = pc / ax.x; }
     return n;
 }
 
 // Material.scatter (raytracer.zig:407-414) for one lane.  unit = normalize(direction) (unused for
 // lambertian), r = Philox block depth+1.  Returns true when the path continues with the scattered ray
 // in L.o/L.d.
-__device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, float len_d, const uint32_t r[4])
+__device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, float len_d, const uint32_t r[4], uint32_t *prof)
 {
     const f3 p = S.p, n = S.n;
     f3 dir;
@@ -108,22 +119,26 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
         reflected = unit - (2.0f * dn_u) * n;
     }
     if (S.kind != K_DIELECTRIC) {
+        prof_block(prof, RT_PB_RIUS);
         // random_in_unit_sphere, raytracer.zig:574-578 -- once for the lambertian and the metal lanes together
         const f3 cube = mk(u32_to_unit_float(r[0]), u32_to_unit_float(r[1]), u32_to_unit_float(r[2]));
         const f3 cn = cube / sqrtf(dot(cube, cube));
         const float cs = u32_to_unit_float(r[3]);
         bool risky;
         float cb = cbrt_unit_fast(cs, risky);                      // bit-identical to cbrt_f32 on the unit grid
-        if (__ballot(risky) != 0ull) cb = cbrt_f32(cs);            // 1 input in 4096: musl's f64 steps decide
+        if (__ballot(risky) != 0ull) { prof_block(prof, RT_PB_CBRT_SLOW); cb = cbrt_f32(cs); }   // 1 input in 4096: musl's f64 steps decide
         const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
         if (S.kind == K_LAMBERTIAN) {                              // Lambertian.scatter, :438-445
+            prof_block(prof, RT_PB_LAMBERTIAN);
             const f3 target = (p + n) + rius;
             dir = target - p;
         } else {                                                   // Metal.scatter, :423-433
+            prof_block(prof, RT_PB_METAL);
             dir = reflected + S.param * rius;
             if (!(dot(dir, n) > 0)) return false;                  // absorbed: the path returns black
         }
     } else {                                                       // Dielectric.scatter, :469-499
+        prof_block(prof, RT_PB_DIELECTRIC);
         const float param = S.param;
         const float ddn = dot(L.d, n);
         f3 on; float ni_over_nt, cos_num;
@@ -239,9 +254,10 @@ struct Outputs {
 // pixel is done -- it writes the pixel out and pulls the next pixel from the global queue (one
 // wave-aggregated atomic for all lanes of the wave that need one).  Render's loops, raytracer.zig:521-528,
 // and trace's, :536-541.  Returns true when a camera ray is to be generated for (L.pix, L.sample).
-__device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane)
+__device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bool &alive, Outputs &O, uint32_t lane, uint32_t *prof)
 {
     if (L.sample >= L.send) {
+        prof_block(prof, RT_PB_DEQUEUE);
         if (L.pix != NOPIX) {                         // (pixel, sample range) finished: this lane is its only writer
             if (P.n_chunks > 1u) {
                 float *dst = O.partial + (size_t)L.part * P.plane_stride + 3ull * L.pix;
@@ -322,7 +338,8 @@ __device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bo
 // consecutive items from it (ballot + popcount rank), and only when the range runs dry does the leader reserve
 // the next P.queue_batch items with ONE atomic on the global head.  (One atomic per item saturates a single
 // counter at this kernel's rate.)
-__device__ __forceinline__ bool advance_prefetch(const TraceParams &P, Lane &L, bool idle, bool &alive, Outputs &O, uint32_t lane)
+__device__ __forceinline__ bool advance_prefetch(const TraceParams &P, Lane &L, bool idle, bool &alive, Outputs &O, uint32_t lane,
+                                                 uint32_t *prof)
 {
     const bool fin = idle && L.sample >= L.send;
     if (fin && L.pix != NOPIX) {                      // item finished: this lane is its only writer
@@ -339,6 +356,7 @@ __device__ __forceinline__ bool advance_prefetch(const TraceParams &P, Lane &L, 
         L.pix = NOPIX;
     }
     if (__ballot(fin && L.nx_pix == NOPIX && !L.dry) != 0ull) {     // wave-uniform: refill every empty slot
+        prof_block(prof, RT_PB_DEQUEUE);
         const bool take = L.nx_pix == NOPIX && !L.dry;
         const unsigned long long m = __ballot(take);
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -420,18 +438,21 @@ __device__ __forceinline__ void shade_and_spawn(const TraceParams &P, Lane &L, b
     float len_d = 1.0f;
     Surface S;
     S.kind = K_LAMBERTIAN;
+    uint32_t *const prof = HIST ? s_hist + RT_HIST_WORDS : nullptr;   // block counters live behind the depth histogram
     if (has_ray) {
         L.nrays += 1;
         if (HIST) atomicAdd(&s_hist[L.depth < 19u ? L.depth : 19u], 1u);
         len_d = sqrtf(a);                             // vector.zig:10-13 length(direction)
         const bool hit = best != NOHIT;
         if (hit && L.depth <= P.max_depth) {          // raytracer.zig:556-558: the cap is tested after the hit
+            prof_block(prof, RT_PB_SURFACE);
             S.p = L.o + best_t * L.d;                 // ray.zig:10-12
-            fetch_surface(best, S);
+            fetch_surface(best, S, prof);
             scatter = true;
         }
-        if (!hit || S.kind != K_LAMBERTIAN) unit = L.d / len_d;    // normalize: three true divides
+        if (!hit || S.kind != K_LAMBERTIAN) { prof_block(prof, RT_PB_UNIT); unit = L.d / len_d; }   // normalize: three true divides
         if (!hit) {                                   // sky, raytracer.zig:569-571
+            prof_block(prof, RT_PB_SKY);
             const float tt = 0.5f * (unit.y + 1.0f);
             const f3 sky = mk((1.0f - tt) + tt * 0.5f, (1.0f - tt) + tt * 0.7f, (1.0f - tt) + tt * 1.0f);
             L.col = L.col + L.thr * sky;
@@ -439,16 +460,18 @@ __device__ __forceinline__ void shade_and_spawn(const TraceParams &P, Lane &L, b
         if (!scatter) { L.sample += 1; has_ray = false; }
     }
     bool gen = false;
-    if (PREFETCH) gen = advance_prefetch(P, L, !has_ray && alive, alive, O, lane);
-    else if (!has_ray && alive) gen = advance_direct(P, L, alive, O, lane);
+    if (PREFETCH) gen = advance_prefetch(P, L, !has_ray && alive, alive, O, lane, prof);
+    else if (!has_ray && alive) gen = advance_direct(P, L, alive, O, lane, prof);
     if (scatter || gen) {
+        prof_block(prof, RT_PB_PHILOX);
         uint32_t r[4];
         philox4x32_10(L.pix, L.sample, scatter ? L.depth + 1u : 0u, 0u, P.key0, P.key1, r);
         if (gen) {
+            prof_block(prof, RT_PB_CAMERA);
             camera_ray(P, L, r);
             has_ray = true;
             O.my_primary += 1;
-        } else if (!scatter_ray(L, S, unit, len_d, r)) {
+        } else if (!scatter_ray(L, S, unit, len_d, r, prof)) {
             L.sample += 1; has_ray = false;
         }
     }
@@ -461,6 +484,8 @@ __device__ __forceinline__ void finish(const Outputs &O, unsigned long long *sta
     if (hist) {
         __syncthreads();
         if (threadIdx.x < 20) atomicAdd(&stats[2 + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+        if (threadIdx.x < 2 * RT_PROF_BLOCKS)
+            atomicAdd(&stats[28 + threadIdx.x], (unsigned long long)s_hist[RT_HIST_WORDS + threadIdx.x]);
     }
 }
 
@@ -471,9 +496,9 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     const float4 *__restrict__ albedo, float *__restrict__ accum, float *__restrict__ partial,
     uint32_t *__restrict__ raycount, uint32_t *__restrict__ queue, unsigned long long *__restrict__ stats)
 {
-    __shared__ uint32_t s_hist[20];
+    __shared__ uint32_t s_hist[RT_HIST_WORDS + 2 * RT_PROF_BLOCKS];
     __shared__ uint32_t s_wq[2 * (BLOCK / 64)];
-    if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
+    if (HIST && threadIdx.x < RT_HIST_WORDS + 2 * RT_PROF_BLOCKS) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (BLOCK / 64)) s_wq[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -488,9 +513,9 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
     uint32_t best = NOHIT;
     for (;;) {
         // resolve the rays of the previous iteration and give every lane its next ray
-        shade_and_spawn<HIST, true>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+        shade_and_spawn<HIST, true>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S, uint32_t *prof) {
             const float4 g = geom[prim], ax = aux[prim], al = albedo[2u * prim], al2 = albedo[2u * prim + 1u];
-            S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax);
+            S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax, prof);
             S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z); S.r0sq = al.w; S.inv_param = al2.x;
         });
         if (__ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
@@ -542,13 +567,13 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 {
     typedef typename std::conditional<LDSN, uint16_t, uint32_t>::type idx_t;
     constexpr int BLOCK = NT;
-    __shared__ uint32_t s_hist[HIST ? 20 : 1];
+    __shared__ uint32_t s_hist[HIST ? RT_HIST_WORDS + 2 * RT_PROF_BLOCKS : 1];
     __shared__ idx_t s_stack[STACK * BLOCK];          // [entry][thread]: a wave's accesses are conflict-free
     __shared__ idx_t s_cand[CAND * BLOCK];
     extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
     const float4 *s_geom = s_scene + (LDSN ? n_nodes * LDS_NODE_STRIDE : 0u);
     __shared__ uint32_t s_wq[2 * (NT / 64)];
-    if (HIST && threadIdx.x < 20) s_hist[threadIdx.x] = 0;
+    if (HIST && threadIdx.x < RT_HIST_WORDS + 2 * RT_PROF_BLOCKS) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
         // the device nodes are already in traversal format (80 bytes, child refs = byte offsets): straight copy.
@@ -612,7 +637,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if (HIST) c_wshade += 1;
             if (node == DONE) {
                 if (HIST && has_ray) c_lshade += 1;
-                shade_and_spawn<HIST, false>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S) {
+                shade_and_spawn<HIST, false>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S, uint32_t *prof) {
                     uint32_t mat;
                     if (KIND == KIND_BVH_TRIANGLES) {
                         const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
@@ -624,7 +649,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     } else {
                         const float4 g = LDSN ? s_geom[prim] : geom[prim];
                         mat = prim;
-                        S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), aux[mat]);
+                        S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), aux[mat], prof);
                     }
                     const float4 ax = aux[mat], al = albedo[2u * mat], al2 = albedo[2u * mat + 1u];
                     S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z); S.r0sq = al.w; S.inv_param = al2.x;
