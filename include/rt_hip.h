@@ -141,6 +141,20 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
 int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
                      float *d_accum_sum, uint32_t *d_raycount, void *stream, rt_stats *stats);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP stream/graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same contract as rt_render_device without the
+ * stats (enqueue only; pass d_raycount for ray counts), but the pass's scratch -- work-queue head, counters and
+ * the per-chunk partial-sum planes -- lives in a fixed RT_NOALLOC_SCRATCH_BYTES device array inside the library
+ * (one copy per GPU, held until the process ends) instead of ctx-owned hipMalloc memory, and the call makes no
+ * hipMalloc/hipFree or other allocating call.  Limit: the planes of one pass, n_chunks * nx*ny*3 floats, must fit
+ * in RT_NOALLOC_SCRATCH_BYTES - 1024; an explicit spp_chunk that needs more returns RT_E_CAP, RT_SPP_CHUNK_AUTO
+ * picks no more chunks than fit (so its sum order can differ from rt_render_device's AUTO), spp_chunk = 0 needs
+ * none.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two contexts)
+ * race; the call clears what it needs at its start. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_device_noalloc(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
+                             float *d_accum_sum, uint32_t *d_raycount, void *stream);
+
 /* The reference's own merge (quirk Q4), for A/B against a Zig render: n_images whole-image renders of
  * cfg->spp_total samples each, image i keyed with seed i*123 (raytracer.zig:600; cfg->seed is ignored), each
  * gamma'd and quantised to u8 (raytracer.zig:527), then the per-channel INTEGER mean of the u8 images

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  
 RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
 RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2
 RT_SPP_CHUNK_AUTO = 0xFFFFFFFF
+RT_NOALLOC_SCRATCH_BYTES = 64 << 20
 RT_FLAG_DEPTH_HISTOGRAM, RT_FLAG_FORCE_BRUTE_FORCE, RT_FLAG_FORCE_BVH = 1, 2, 4
 
 f32p = C.POINTER(C.c_float)
@@ -49,7 +50,7 @@ class rt_stats(C.Structure):
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
     "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts",
-    "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
+    "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
     "rt_selftest_math", "rt_selftest_cbrt_grid",
 ]
@@ -110,6 +111,8 @@ def load():
     L.rt_render_reference_style.restype = C.c_int
     L.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
     L.rt_render_device.restype = C.c_int
+    L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp]
+    L.rt_render_device_noalloc.restype = C.c_int
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_tonemap_device.restype = C.c_int
     L.rt_camera_basic.argtypes = [C.POINTER(rt_camera)]

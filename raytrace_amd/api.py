@@ -296,6 +296,14 @@ class Context:
         self._check(rc, "rt_render_device")
         return _stats_tuple(st) if want_stats else None
 
+    def render_device_noalloc(self, cam, cfg, d_accum_sum, d_raycount=0, stream=0):
+        """rt_render_device_noalloc: rt_render_device's work with the library's fixed scratch array instead of
+        ctx-owned allocations; enqueue only (no stats)."""
+        rc = self._L.rt_render_device_noalloc(self._h, C.byref(cam.to_abi()), C.byref(cfg), C.c_void_p(d_accum_sum),
+                                              C.c_void_p(d_raycount) if d_raycount else None,
+                                              C.c_void_p(stream) if stream else None)
+        self._check(rc, "rt_render_device_noalloc")
+
     def tonemap_device(self, d_accum_sum, n_pixels, spp_total, d_mean=0, d_rgb8=0, stream=0):
         rc = self._L.rt_tonemap_device(self._h, C.c_void_p(d_accum_sum), n_pixels, spp_total,
                                        C.c_void_p(d_mean) if d_mean else None,

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -40,7 +41,24 @@ struct rt_ctx {
     float       *d_mean = nullptr;   size_t mean_cap = 0;
     uint8_t     *d_rgb8 = nullptr;   size_t rgb8_cap = 0;
     float       *d_gather = nullptr; size_t gather_cap = 0;    // rt_render_multi root: peers' sum buffers
+    unsigned char *noalloc_scratch = nullptr;  // this device's copy of `scratch` (rt_render_device_noalloc)
 };
+
+// ---- rt_render_device_noalloc's scratch -----------------------------------------------------------------
+// A trace pass needs device memory beyond its inputs and outputs: the work-queue head, the counters and the
+// per-chunk partial-sum planes.  The other entry points take it from the ctx (hipMalloc, grown on demand); the
+// no-alloc entry point takes it from this file-scope device array.  Every GPU the library runs on holds its own
+// copy, at its own address, until the process ends.  `scratch` is only a host-side handle here: the device
+// address comes from hipGetSymbolAddress (once per device, in rt_create, with that device current) and is what
+// kernels, memsets and copies are given.
+constexpr size_t NOALLOC_QUEUE_OFF = 0, NOALLOC_STATS_OFF = 256, NOALLOC_PARTIAL_OFF = 1024;
+static_assert(NOALLOC_STATS_OFF + sizeof(unsigned long long) * RT_STATS_WORDS <= NOALLOC_PARTIAL_OFF, "scratch header layout");
+static_assert(RT_NOALLOC_SCRATCH_BYTES > NOALLOC_PARTIAL_OFF && RT_NOALLOC_SCRATCH_BYTES % 256 == 0, "scratch size");
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char *g_scratch_ptr[MAX_DEVICES] = { nullptr };   // per device: each GPU has its own copy
 
 namespace {
 
@@ -105,7 +123,10 @@ int check_config(const rt_config *cfg)
     return RT_OK;
 }
 
-void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, bool triangles)
+// max_planes bounds the number of partial-sum planes (0 = no bound): RT_SPP_CHUNK_AUTO then picks a chunk size that
+// needs no more than that many; an explicit spp_chunk is taken as given (the caller checks p.n_chunks).
+void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, bool triangles,
+                 uint64_t max_planes = 0)
 {
     std::memset(&p, 0, sizeof p);
     for (int k = 0; k < 3; ++k) {
@@ -137,13 +158,17 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
             uint64_t nc = (want_items + pixel_items - 1) / pixel_items;
             if (nc > n_spp / 4) nc = n_spp / 4;
             if (nc > 64) nc = 64;
+            if (max_planes != 0 && nc > max_planes) nc = max_planes;
             if (nc > 1) chunk = (uint32_t)((n_spp + nc - 1) / nc);
         }
     }
     p.spp_chunk = 0; p.chunk0 = 0; p.n_chunks = 1;
     if (chunk != 0 && n_spp > 0) {
         const uint32_t c0 = cfg->spp_begin / chunk, c1 = (uint32_t)(((uint64_t)cfg->spp_end + chunk - 1) / chunk);
-        if (c1 - c0 > 1) { p.spp_chunk = chunk; p.chunk0 = c0; p.n_chunks = c1 - c0; }
+        // (a range that starts inside a chunk touches one chunk more than its length suggests: AUTO then gives up
+        // chunking rather than exceed the bound)
+        const bool over = cfg->spp_chunk == RT_SPP_CHUNK_AUTO && max_planes != 0 && c1 - c0 > max_planes;
+        if (c1 - c0 > 1 && !over) { p.spp_chunk = chunk; p.chunk0 = c0; p.n_chunks = c1 - c0; }
     }
     p.plane_stride = (size_t)cfg->nx * cfg->ny * 3;
     p.queue_batch = p.n_chunks > 1 ? 128u : 64u;    // coarse items (whole pixels): reserve less, the tail is long enough
@@ -181,35 +206,57 @@ TraceKernel pick_kernel(const rt_ctx *ctx)
     return ctx->n_sph <= BRUTE_FORCE_MAX_SPHERES ? RT_K_BRUTE_SPHERES : RT_K_BVH_SPHERES;
 }
 
-// enqueue one trace pass on `stream`; timing events are recorded around the kernel
+// The device memory a trace pass needs beyond its inputs and outputs: the work-queue head, the counters and the
+// planes of per-chunk partial sums.  The ctx's own (grown on demand with hipMalloc), or a fixed one the caller
+// brings (rt_render_device_noalloc: partial_cap floats, never grown).
+struct TraceScratch {
+    uint32_t           *queue;
+    unsigned long long *stats;
+    float              *partial;       // null: the ctx's d_partial, grown on demand
+    size_t              partial_cap;   // floats (fixed scratch only)
+    bool                fixed;
+};
+
+// enqueue one trace pass on `stream`; timing events are recorded around the kernel (not for a fixed scratch:
+// that path is for callers under stream capture)
 int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
-                  uint32_t *d_raycount, hipStream_t stream)
+                  uint32_t *d_raycount, hipStream_t stream, const TraceScratch *fixed = nullptr)
 {
     if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
     TraceParams p;
-    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
+    const size_t plane = (size_t)cfg->nx * cfg->ny * 3;
+    uint64_t max_planes = 0;     // fixed scratch: as many planes as fit, at least "one" (= no chunking)
+    if (fixed) { max_planes = fixed->partial_cap / plane; if (max_planes < 1) max_planes = 1; }
+    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0, max_planes);
+    if (fixed && p.n_chunks > 1 && (uint64_t)plane * p.n_chunks > fixed->partial_cap) return RT_E_CAP;
+    uint32_t *const d_queue = fixed ? fixed->queue : ctx->d_queue;
+    unsigned long long *const d_stats = fixed ? fixed->stats : ctx->d_stats;
+    HIP_TRY(ctx, hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
     DeviceScene s;
     s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;
     s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth;
     ctx->last_kernel = pick_kernel(ctx);
+    float *d_partial = fixed ? fixed->partial : ctx->d_partial;
     if (p.n_chunks > 1) {        // scratch planes for the per-chunk partial sums (every cell is written)
-        const int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, p.plane_stride * p.n_chunks);
-        if (rc != RT_OK) return rc;
+        if (!fixed) {
+            const int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, p.plane_stride * p.n_chunks);
+            if (rc != RT_OK) return rc;
+            d_partial = ctx->d_partial;
+        }
         if (p.x0 != 0 || p.y0 != 0 || p.x1 != cfg->nx || p.y1 != cfg->ny)   // tiles leave cells untouched
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_partial, 0, p.plane_stride * p.n_chunks * sizeof(float), stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_partial, 0, p.plane_stride * p.n_chunks * sizeof(float), stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (!fixed) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (cfg->spp_end > cfg->spp_begin) {
-        HIP_TRY(ctx, rt_launch_trace(ctx->last_kernel, p, s, d_accum_sum, ctx->d_partial, d_raycount, ctx->d_queue,
-                                     ctx->d_stats, hist, ctx->num_cus, stream));
+        HIP_TRY(ctx, rt_launch_trace(ctx->last_kernel, p, s, d_accum_sum, d_partial, d_raycount, d_queue,
+                                     d_stats, hist, ctx->num_cus, stream));
         if (p.n_chunks > 1)
-            HIP_TRY(ctx, rt_launch_reduce_chunks(d_accum_sum, ctx->d_partial, cfg->nx * cfg->ny, p.n_chunks,
+            HIP_TRY(ctx, rt_launch_reduce_chunks(d_accum_sum, d_partial, cfg->nx * cfg->ny, p.n_chunks,
                                                  p.plane_stride, stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    if (!fixed) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     return RT_OK;
 }
 
@@ -252,7 +299,7 @@ const char *rt_strerror(int code)
     case RT_E_NOMEM: return "out of memory";
     case RT_E_STATE: return "invalid state (no scene uploaded?)";
     case RT_E_IO: return "I/O error";
-    case RT_E_CAP: return "output capacity too small";
+    case RT_E_CAP: return "capacity too small (output buffer, or the fixed scratch of rt_render_device_noalloc)";
     default: return "unknown error";
     }
 }
@@ -287,6 +334,17 @@ int rt_create(int device, rt_ctx **out)
         if ((e = hipMalloc((void **)&ctx->d_queue, 256)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_NOMEM; break; }
         if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * RT_STATS_WORDS)) != hipSuccess) {
             ctx->last_hip = e; rc = RT_E_NOMEM; break;
+        }
+        {   // this device's address of `scratch` (device `device` is current)
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            unsigned char *ptr = device < MAX_DEVICES ? g_scratch_ptr[device] : nullptr;
+            if (!ptr) {
+                if ((e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch))) != hipSuccess || !ptr) {
+                    ctx->last_hip = e; rc = RT_E_HIP; break;
+                }
+                if (device < MAX_DEVICES) g_scratch_ptr[device] = ptr;
+            }
+            ctx->noalloc_scratch = ptr;
         }
     } while (0);
     if (rc != RT_OK) { rt_destroy(ctx); return rc; }
@@ -462,6 +520,25 @@ int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, fl
     if (rc != RT_OK) return rc;
     if (stats) return read_stats(ctx, stream, stats);
     return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *d_accum_sum,
+                             uint32_t *d_raycount, void *stream_)
+{
+    if (!ctx || !cam || !d_accum_sum) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    if (!ctx->noalloc_scratch) return RT_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    unsigned char *ptr = ctx->noalloc_scratch;            // the device address, never the array's name
+    TraceScratch sc;
+    sc.queue = (uint32_t *)(ptr + NOALLOC_QUEUE_OFF);
+    sc.stats = (unsigned long long *)(ptr + NOALLOC_STATS_OFF);
+    sc.partial = (float *)(ptr + NOALLOC_PARTIAL_OFF);
+    sc.partial_cap = (RT_NOALLOC_SCRATCH_BYTES - NOALLOC_PARTIAL_OFF) / sizeof(float);
+    sc.fixed = true;
+    return enqueue_trace(ctx, cam, cfg, d_accum_sum, d_raycount, stream, &sc);   // RT_E_CAP: planes do not fit
 }
 
 int rt_tonemap_device(rt_ctx *ctx, const float *d_accum_sum, uint32_t n_pixels, uint32_t spp_total,
