@@ -74,7 +74,10 @@ typedef struct {
     uint32_t spp_chunk;              /* 0: one running sum per pixel, samples added in order as trace does
                                         (raytracer.zig:535-541); C > 0: global samples [k*C,(k+1)*C) are summed per
                                         chunk and the chunk sums added in order (more, smaller work items: a shorter
-                                        tail); RT_SPP_CHUNK_AUTO: the library picks C */
+                                        tail); RT_SPP_CHUNK_AUTO: the library picks C from nx*ny and the length of
+                                        [spp_begin,spp_end), so the f32 sum ORDER then depends on the image size and
+                                        on how a job splits its samples (1-GPU and N-GPU images agree to ~1e-6, not
+                                        bit for bit; pass an explicit C where bits must not depend on the split) */
 } rt_config;
 #define RT_SPP_CHUNK_AUTO 0xFFFFFFFFu
 
@@ -101,6 +104,18 @@ void rt_destroy(rt_ctx *ctx);
 const char *rt_strerror(int code);
 int  rt_last_hip_error(const rt_ctx *ctx);   /* hipError_t of the last failing HIP call */
 int  rt_set_flags(rt_ctx *ctx, uint32_t flags);
+
+/* Kernel tuning knobs (no reference counterpart; the reference has no flags at all).  Per ctx, 0 = the
+ * library's default.  None of them changes a result bit except through nothing: the image is a function of the
+ * scene, camera and rt_config only (tests/test_gpu_parity.py compares variants bit for bit). */
+typedef struct {
+    uint32_t queue_batch;         /* work items a wave reserves per global atomic: 64..256 (default 64, 128 when chunked) */
+    uint32_t flush_lanes;         /* BVH kernels: run a batch of exact tests when this many lanes hold a candidate: 1..65 (24) */
+    uint32_t keep_traversing;     /* BVH kernels: leave the traversal loop when fewer lanes than this traverse: 1..64 (8; triangles 16) */
+    uint32_t force_global_scene;  /* 1: never stage a small scene in LDS */
+    uint32_t bvh_depth_cap;       /* BVH builder: cap on inner-node levels, 8..32 (24); applies to the NEXT rt_upload_scene */
+} rt_tuning;
+int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaults */
 
 /* ---- scene upload: the `world: Hittable` argument of Render (raytracer.zig:517) ------------- */
 /* Exactly one of spheres / triangles per scene; `materials` (kind, r, g, b, param) is required with

@@ -468,22 +468,33 @@ static uint32_t tri_build(orc_world *w, uint32_t first, uint32_t count)
     n->left = l; n->right = r; n->count = 0;
     return id;
 }
+/* Cull test of the checker's triangle BVH.  It must never reject a box that holds a triangle orc_triangle_hit would
+ * accept, for any ray origin: Moller-Trumbore's barycentrics are off by a few ulps of |o - v0| ACROSS the ray, and
+ * the slab arithmetic rounds relative to the distance.  So the ray is widened into a cone of half-angle 2^-14
+ * (f64 arithmetic, plain formulas; speed does not matter here): at parameter t the box is grown by g t, g = 2^-14 |d|.
+ * Axis k: o_k + t (d_k + g) >= lo_k and o_k + t (d_k - g) <= hi_k.  The nodes' static padding (tri_build) covers
+ * origins next to a triangle. */
 static int tri_box_hit(const tri_node *n, orc_v3 ro, orc_v3 rd, float t_min, float t_max)
 {
-    const float o[3] = { ro.x, ro.y, ro.z }, d[3] = { rd.x, rd.y, rd.z };
-    float lo = t_min, hi = t_max;
+    const double o[3] = { ro.x, ro.y, ro.z }, d[3] = { rd.x, rd.y, rd.z };
+    const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double g = len * (1.0 / 16384.0);
+    double lo = t_min, hi = t_max;
+    if (!(len > 0.0) || !(len < 1e300)) return 1;          /* degenerate ray: no culling (the exact tests reject it) */
     for (int k = 0; k < 3; k++) {
-        if (d[k] == 0.0f) { if (o[k] < n->lo[k] || o[k] > n->hi[k]) return 0; continue; }
-        float inv = 1.0f / d[k];
-        float t0 = (n->lo[k] - o[k]) * inv, t1 = (n->hi[k] - o[k]) * inv;
-        if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
-        /* widen by a few ulps: conservative */
-        t0 -= fabsf(t0) * 4e-7f; t1 += fabsf(t1) * 4e-7f;
-        if (t0 > lo) lo = t0;
-        if (t1 < hi) hi = t1;
-        if (hi < lo) return 0;
+        /* upper edge of the cone, slope d_k + g, must reach lo_k; lower edge, slope d_k - g, must stay below hi_k */
+        const double up = d[k] + g, dn = d[k] - g;
+        const double a = (double)n->lo[k] - o[k], b = (double)n->hi[k] - o[k];
+        /* t * up >= a */
+        if (up > 0) { if (a / up > lo) lo = a / up; }
+        else if (up < 0) { if (a / up < hi) hi = a / up; }
+        else if (a > 0) return 0;
+        /* t * dn <= b */
+        if (dn > 0) { if (b / dn < hi) hi = b / dn; }
+        else if (dn < 0) { if (b / dn > lo) lo = b / dn; }
+        else if (b < 0) return 0;
     }
-    return 1;
+    return !(hi < lo - 1e-9 * fabs(lo));
 }
 
 orc_world *orc_world_create(const orc_sphere *sph, uint32_t n_sph,
@@ -620,7 +631,16 @@ static int world_hit(const hit_ctx *c, orc_v3 ro, orc_v3 rd, float t_min, float 
         if (c->traversal == ORC_TRAV_BVH_REF) have = node_hit(c, c->w->bvh, ro, rd, t_min, t_max, &best);
         else have = list_hit(c, ro, rd, t_min, t_max, &best);
     }
-    if (c->w->n_tri) tri_traverse(c, ro, rd, t_min, &best, &have);
+    if (c->w->n_tri && c->traversal == ORC_TRAV_BRUTE) {
+        for (uint32_t ti = 0; ti < c->w->n_tri; ti++) {       /* every triangle, index order: the definition */
+            hit_rec rec;
+            c->cnt->tri_tests++;
+            if (orc_triangle_hit(&c->w->tri[ti], ro, rd, t_min, FLT_MAX, &rec.t, &rec.p, &rec.normal)) {
+                rec.prim = c->w->n_sph + ti; rec.material = c->w->tri[ti].material;
+                if (!have || rec.t < best.t) { best = rec; have = 1; }
+            }
+        }
+    } else if (c->w->n_tri) tri_traverse(c, ro, rd, t_min, &best, &have);
     if (have) *out = best;
     return have;
 }

@@ -52,8 +52,11 @@ typedef struct {
 } orc_camera;
 
 /* traversal modes */
-enum { ORC_TRAV_LIST = 0,    /* hittableList semantics, raytracer.zig:88-115 (normative) */
-       ORC_TRAV_BVH_REF = 1  /* build_BVH + 2-axis AABB, raytracer.zig:117-395 (quirks Q1, Q2) */ };
+enum { ORC_TRAV_LIST = 0,    /* hittableList semantics, raytracer.zig:88-115 (normative); triangles: the checker's own
+                                conservative BVH (a speed-up that returns the list answer) */
+       ORC_TRAV_BVH_REF = 1, /* build_BVH + 2-axis AABB, raytracer.zig:117-395 (quirks Q1, Q2) */
+       ORC_TRAV_BRUTE = 2    /* spheres as LIST; triangles as a plain loop over every triangle in index order: no culling
+                                structure at all (small meshes; pins the speed-up above) */ };
 
 typedef struct {
     uint32_t nx, ny;

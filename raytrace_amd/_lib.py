@@ -41,6 +41,11 @@ class rt_config(C.Structure):
                 ("row_offset_q3", C.c_uint32), ("spp_chunk", C.c_uint32)]
 
 
+class rt_tuning(C.Structure):
+    _fields_ = [("queue_batch", C.c_uint32), ("flush_lanes", C.c_uint32), ("keep_traversing", C.c_uint32),
+                ("force_global_scene", C.c_uint32), ("bvh_depth_cap", C.c_uint32)]
+
+
 class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("rays_by_depth", C.c_uint64 * 20)]
@@ -48,7 +53,7 @@ class rt_stats(C.Structure):
 
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_upload_scene",
+    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_set_tuning", "rt_upload_scene",
     "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts",
     "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
@@ -87,6 +92,8 @@ def load():
     L.rt_last_hip_error.restype = C.c_int
     L.rt_set_flags.argtypes = [vp, C.c_uint32]
     L.rt_set_flags.restype = C.c_int
+    L.rt_set_tuning.argtypes = [vp, C.POINTER(rt_tuning)]
+    L.rt_set_tuning.restype = C.c_int
     L.rt_upload_scene.argtypes = [vp, C.POINTER(rt_spheres), C.POINTER(rt_triangles), C.POINTER(rt_spheres)]
     L.rt_upload_scene.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]

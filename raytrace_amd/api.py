@@ -10,7 +10,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import RtError, rt_camera, rt_config, rt_spheres, rt_stats
+from ._lib import RtError, rt_camera, rt_config, rt_spheres, rt_stats, rt_tuning
 
 
 def _f32(a):
@@ -226,6 +226,11 @@ class Context:
 
     def set_flags(self, flags):
         self._check(self._L.rt_set_flags(self._h, flags), "rt_set_flags")
+
+    def set_tuning(self, queue_batch=0, flush_lanes=0, keep_traversing=0, force_global_scene=0, bvh_depth_cap=0):
+        """rt_set_tuning: kernel tuning knobs of this ctx, 0 = default (bvh_depth_cap applies to the next upload)."""
+        t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap)
+        self._check(self._L.rt_set_tuning(self._h, C.byref(t)), "rt_set_tuning")
 
     def upload_scene(self, spheres=None, triangles=None, materials=None):
         sv = spheres.view() if spheres is not None else None

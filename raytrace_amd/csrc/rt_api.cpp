@@ -24,6 +24,7 @@ struct rt_ctx {
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
+    rt_tuning    tuning = { 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
     int          last_hip = 0;
     // scene (one kind of primitive at a time: spheres or triangles)
     float4      *d_geom = nullptr, *d_tri = nullptr, *d_aux = nullptr, *d_albedo = nullptr, *d_bvh = nullptr;
@@ -126,7 +127,7 @@ int check_config(const rt_config *cfg)
 // max_planes bounds the number of partial-sum planes (0 = no bound): RT_SPP_CHUNK_AUTO then picks a chunk size that
 // needs no more than that many; an explicit spp_chunk is taken as given (the caller checks p.n_chunks).
 void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, bool triangles,
-                 uint64_t max_planes = 0)
+                 const rt_tuning &tune, uint64_t max_planes = 0)
 {
     std::memset(&p, 0, sizeof p);
     for (int k = 0; k < 3; ++k) {
@@ -172,10 +173,7 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     }
     p.plane_stride = (size_t)cfg->nx * cfg->ny * 3;
     p.queue_batch = p.n_chunks > 1 ? 128u : 64u;    // coarse items (whole pixels): reserve less, the tail is long enough
-    if (const char *e = std::getenv("RT_HIP_QUEUE_BATCH")) {         // tuning knob
-        const int v = std::atoi(e);
-        if (v >= 64 && v <= 4096) p.queue_batch = (uint32_t)v;
-    }
+    if (tune.queue_batch) p.queue_batch = tune.queue_batch;
     p.n_items = (uint32_t)(pixel_items * p.n_chunks);
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
@@ -183,15 +181,9 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     // scenes from LDS 8; the triangle-mesh scene, whose steps wait on global memory, 16)
     p.keep_traversing = triangles ? 16 : 8;
     p.flush_lanes = 24;                              // 65 = only the "queue nearly full" rule
-    if (const char *e = std::getenv("RT_HIP_FLUSH_LANES")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 65) p.flush_lanes = (uint32_t)v;
-    }
-    p.force_global_scene = std::getenv("RT_HIP_GLOBAL_SCENE") ? 1u : 0u;
-    if (const char *e = std::getenv("RT_HIP_KEEP_TRAVERSING")) {    // tuning knob (1..64)
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 64) p.keep_traversing = (uint32_t)v;
-    }
+    if (tune.flush_lanes) p.flush_lanes = tune.flush_lanes;
+    p.force_global_scene = tune.force_global_scene ? 1u : 0u;
+    if (tune.keep_traversing) p.keep_traversing = tune.keep_traversing;
 }
 
 // Spheres up to this count are traced by the brute-force kernel (one scalar-fed loop, no divergence);
@@ -227,7 +219,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     const size_t plane = (size_t)cfg->nx * cfg->ny * 3;
     uint64_t max_planes = 0;     // fixed scratch: as many planes as fit, at least "one" (= no chunking)
     if (fixed) { max_planes = fixed->partial_cap / plane; if (max_planes < 1) max_planes = 1; }
-    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0, max_planes);
+    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0, ctx->tuning, max_planes);
     if (fixed && p.n_chunks > 1 && (uint64_t)plane * p.n_chunks > fixed->partial_cap) return RT_E_CAP;
     uint32_t *const d_queue = fixed ? fixed->queue : ctx->d_queue;
     unsigned long long *const d_stats = fixed ? fixed->stats : ctx->d_stats;
@@ -377,6 +369,20 @@ int rt_set_flags(rt_ctx *ctx, uint32_t flags)
     return RT_OK;
 }
 
+int rt_set_tuning(rt_ctx *ctx, const rt_tuning *t)
+{
+    if (!ctx) return RT_E_ARG;
+    const rt_tuning def = { 0, 0, 0, 0, 0 };
+    if (!t) t = &def;
+    // queue_batch: every wave reserves at most two batches past the end of the queue, and check_config leaves
+    // 2^24 item numbers of headroom: 16384 resident waves x 2 x 256 stays inside it
+    if (t->queue_batch && (t->queue_batch < 64 || t->queue_batch > 256)) return RT_E_ARG;
+    if (t->flush_lanes > 65 || t->keep_traversing > 64) return RT_E_ARG;
+    if (t->bvh_depth_cap && (t->bvh_depth_cap < 8 || t->bvh_depth_cap > 32)) return RT_E_ARG;
+    ctx->tuning = *t;
+    return RT_OK;
+}
+
 static int upload_vec(rt_ctx *ctx, float4 *&dst, const std::vector<float4> &src)
 {
     if (src.empty()) return RT_OK;
@@ -435,8 +441,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 prims.push_back(rtbvh::triangle_prim(a, b, c));
             }
         }
-        int depth_cap = 24;                                        // 24-entry stacks: 5 workgroups per CU instead of 3
-        if (const char *e = std::getenv("RT_HIP_BVH_DEPTH_CAP")) { const int v = std::atoi(e); if (v >= 8 && v <= 32) depth_cap = v; }
+        const int depth_cap = ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
         const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
         if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
         // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)

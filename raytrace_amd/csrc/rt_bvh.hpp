@@ -196,16 +196,19 @@ inline bool validate(const Tree &t, const std::vector<Prim> &prims)
     return true;
 }
 
-// Conservative padding: the box test may never cull a primitive its exact test would accept.  The
-// slab arithmetic carries a few ulps of the coordinates involved; pad by 1e-3 of the size plus 1e-5 of
-// the coordinate magnitude.
+// Conservative padding: the box test may never cull a primitive its exact test would accept.  The static part
+// is here -- 1.25e-3 of the size (covers ray origins on or inside the primitive: the exact tests' own slop there is
+// a few ulps of the size, and the cone below needs 2^-10 of the size of slack at the near plane) plus 1e-5 of the
+// coordinate magnitude (the cancellation error of the slab arithmetic, 2^-24 |o_k|, when plane and origin are
+// close).  The part that grows with the distance of the ray origin is applied per ray by the kernels, which test
+// a cone instead of a line (rt_kernels.hip, RT_CONE_*).
 inline Prim sphere_prim(float cx, float cy, float cz, float radius)
 {
     Prim p;
     const float c[3] = { cx, cy, cz };
     const float r = std::fabs(radius);
     for (int k = 0; k < 3; ++k) {
-        const float pad = 1e-3f * r + 1e-5f * (std::fabs(c[k]) + r) + 1e-30f;
+        const float pad = 1.25e-3f * r + 1e-5f * (std::fabs(c[k]) + r) + 1e-30f;
         p.box.lo[k] = c[k] - r - pad; p.box.hi[k] = c[k] + r + pad; p.c[k] = c[k];
     }
     return p;
@@ -220,7 +223,7 @@ inline Prim triangle_prim(const float v0[3], const float v1[3], const float v2[3
     }
     for (int k = 0; k < 3; ++k) {
         const float lo = std::min(v0[k], std::min(v1[k], v2[k])), hi = std::max(v0[k], std::max(v1[k], v2[k]));
-        const float pad = 1e-3f * ext + 1e-5f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f;
+        const float pad = 1.25e-3f * ext + 1e-5f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f;
         p.box.lo[k] = lo - pad; p.box.hi[k] = hi + pad;
         p.c[k] = (v0[k] + v1[k] + v2[k]) * (1.0f / 3.0f);
     }

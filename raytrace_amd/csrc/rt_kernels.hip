@@ -205,8 +205,23 @@ __device__ __forceinline__ void triangle_exact(f3 v0, f3 v1, f3 v2, uint32_t pri
 }
 
 // Slab test of both (padded) child boxes of a node in FMA form: plane distance = plane*inv - o*inv (noi = -(o*inv)).
-// It only culls, so it may round differently from the CPU: the padding covers it (rt_bvh.hpp).  Two things make it
-// cheap:
+// It only CULLS, and it must never cull a primitive whose exact test would accept the ray -- for ANY ray origin.
+// Two things can make the exact tests accept a ray that misses the primitive's true shape:
+//   * the f32 discriminant of Sphere.hit, b*b - a*c, carries an absolute error of up to ~16 u |oc|^2 |d|^2
+//     (u = 2^-24, oc = origin - center): the test accepts rays that pass within sqrt(r^2 + 16 u |oc|^2) of the
+//     centre, i.e. up to 2^-10 |oc| outside the sphere when the origin is far away (at |oc| = 10^4 r that is ten
+//     radii: the reference's own arithmetic draws a distant sphere as a blob).  Moller-Trumbore's barycentrics
+//     are off by a few u |o - v0| across the ray;
+//   * the slab arithmetic itself rounds: relative 2^-23 of the distance, plus 2^-24 |o_k| where plane - o cancels.
+// So the ray is widened into a CONE of half-angle RT_CONE (per primitive kind) before the slab test: near planes
+// are tested with inv_near = 1 / (|d_k| + g), far planes with inv_far = 1 / (|d_k| - g), g = RT_CONE * |d| -- the
+// box grows by RT_CONE * distance, which covers both items above at every distance.  An axis that lies within the
+// cone's own width of perpendicular to the ray (|d_k| <= g) has no far bound but a second near bound (ray_splat);
+// that term costs five more instructions per step and runs only while some lane of the wave holds such a ray (about
+// 1 ray in 300 for spheres, 1 in 20 000 for triangles).  The static padding of the boxes (rt_bvh.hpp: 1.25e-3 of the
+// size, 1e-5 of the coordinate) covers origins on or inside the primitive and the cancellation term.  Otherwise no
+// extra instruction per step: only the operands of the six packed FMAs differ between near and far.
+// What makes a step cheap:
 // packed FMAs (v_pk_fma_f32: the two boxes' planes of one axis in one issue slot), and no min/max per axis: the
 // device node (80 bytes, rt_kernels.h) stores every axis as {hi0, hi1, lo0, lo1, hi0, hi1}, and a lane reads its 16 bytes at +8 when its ray runs
 // up that axis and at +0 when it runs down, so the first pair it gets is always the NEAR planes of the two
@@ -217,27 +232,128 @@ __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+constexpr float RT_CONE_SPHERES = 0x1.08p-10f;      // sqrt(15.5 u) = 0.97 * 2^-10, plus 6 % for the slab rounding, the centre's rounding and second-order terms
+// Moller-Trumbore: u and v are off by ~6 u |o - v0| / (|e| sin(phi) cos(theta)) (phi the triangle's corner angle, theta the
+// angle between ray and normal), i.e. ~6 u |o - v0| / (sin(phi) cos(theta)) in space: 2^-14 covers sin(phi) cos(theta) >= 0.006.
+// (A ray within a third of a degree of a triangle's plane is beyond any fixed cone; such a ray would also have to pass within
+// the error's reach of the triangle's edge and outside its padded box -- not seen in 10^9-ray whole-image comparisons.)
+constexpr float RT_CONE_TRIANGLES = 0x1.0p-14f;
 struct RaySplat {
-    v2f      ix, iy, iz, nx, ny, nz;   // {inv.x, inv.x} ... {noi.z, noi.z}: the packed FMAs' ray operands
-    uint32_t ox, oy, oz;               // byte offset of the lane's {near pair, far pair} of each axis inside a node
+    v2f      nx, ny, nz;   // near planes of axis k: {inv_near.k, -(o.k * inv_near.k)}
+    v2f      fx, fy, fz;   // far planes: {inv_far.k, -(o.k * inv_far.k)}; {0, T_MAX} on an axis that lies inside the cone's width of
+                           // perpendicular to the ray (|d_k| <= g): the cone then never leaves the slab, there is no far bound ...
+    v2f      ex, ey, ez;   // ... but a second LOWER bound, from the far plane: the cone has to open up to the slab first.  {inv, noi}
+                           // on such an axis, {0, -T_MAX} otherwise.  Evaluated only while some lane of the wave has such an axis.
+    uint32_t ox, oy, oz;   // byte offset of the lane's {near pair, far pair} of each axis inside a node
+    bool     perp;         // this ray has an axis of the second kind
 };
+// The ray operands of the slab test for one ray (see above).  a = dot(d, d).  Cone condition on axis k at parameter t:
+// o_k + t (d_k - g) <= hi_k and o_k + t (d_k + g) >= lo_k (the cone's lower and upper edge against the slab).  With
+// s = sign(d_k) and |d_k| > g this is the usual pair "t >= (near - o) / (s (|d_k| + g)), t <= (far - o) / (s (|d_k| - g))";
+// with |d_k| <= g the second one turns into a lower bound as well, t >= (far - o) / (s (|d_k| - g)) (denominator < 0).
+// Common case, x = g / |d_k| < 1/2 on every axis: one reciprocal per axis, inv = 1 / d_k, and the two bounds
+// 1 / (|d_k| + g) >= (1 - x) |inv| and 1 / (|d_k| - g) <= (1 + 2 x) |inv| (looser by at most the cone's own width).
+// Otherwise (1 ray in 150 for spheres) the lane's steep axes get their exact reciprocals.
+__device__ __forceinline__ void ray_splat(RaySplat &R, f3 o, f3 d, float a, float cone)
+{
+    // g >= cone * |d|: the approximate sqrt is within 1 ulp, the cone constants carry the margin
+    const float g = cone * __builtin_amdgcn_sqrtf(a);
+    const float dk[3] = { d.x, d.y, d.z }, ok[3] = { o.x, o.y, o.z };
+    v2f n[3], f[3];
+    float xmax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float inv = __builtin_amdgcn_rcpf(dk[k]);
+        const float x = g * __builtin_fabsf(inv);
+        const float rn = __builtin_fmaf(-x, inv, inv), rf = __builtin_fmaf(x + x, inv, inv);
+        n[k] = (v2f){ rn, -(ok[k] * rn) };
+        f[k] = (v2f){ rf, -(ok[k] * rf) };
+        xmax = fmaxf(xmax, x);
+    }
+    R.ex = R.ey = R.ez = (v2f){ 0.0f, -T_MAX };
+    bool perp = false;
+    const bool steep = !(xmax < 0.5f);                  // also NaN and infinity (a zero direction component)
+    if (__ballot(steep) != 0ull) {
+        if (steep) {
+            v2f e[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t sgn = __float_as_uint(dk[k]) & 0x80000000u;
+                const float ad = __builtin_fabsf(dk[k]);
+                const float df = ad - g;
+                const bool bounded = df > 1e-30f;
+                const float rn = __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(fmaxf(ad + g, 1e-30f))) ^ sgn);
+                const float rf = __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(bounded ? df : fminf(df, -1e-30f))) ^ sgn);
+                n[k] = (v2f){ rn, -(ok[k] * rn) };
+                f[k] = bounded ? (v2f){ rf, -(ok[k] * rf) } : (v2f){ 0.0f, T_MAX };
+                e[k] = bounded ? (v2f){ 0.0f, -T_MAX } : (v2f){ rf, -(ok[k] * rf) };
+                perp = perp || !bounded;
+            }
+            R.ex = e[0]; R.ey = e[1]; R.ez = e[2];
+        }
+    }
+    R.nx = n[0]; R.ny = n[1]; R.nz = n[2];
+    R.fx = f[0]; R.fy = f[1]; R.fz = f[2];
+    R.perp = perp;
+    // running up an axis (sign bit clear): near = lo, the pair at +8; running down: near = hi, at +0
+    R.ox = ((__float_as_uint(d.x) >> 31) ^ 1u) << 3;
+    R.oy = 24u + (((__float_as_uint(d.y) >> 31) ^ 1u) << 3);
+    R.oz = 48u + (((__float_as_uint(d.z) >> 31) ^ 1u) << 3);
+}
 constexpr uint32_t NODE_AXIS_BYTES = 24, NODE_REFS_OFFSET = 72;   // layout of RT_NODE_BYTES = 80 (rt_kernels.h)
 struct __attribute__((aligned(8))) PlanePairs { v2f near_, far_; };   // 16 bytes at 8-byte alignment: one ds_read2_b64 / global_load_dwordx4
+// The whole test is ONE asm statement: hipcc pads every boundary between an asm statement and the next instruction that
+// touches its outputs with an s_nop (it cannot see that nothing in here is a transcendental), which as separate
+// one-instruction statements cost eight issue slots per step.  v_pk_fma_f32 with op_sel broadcasts the halves of a
+// ray operand pair, {p0, p1} * op.x + op.y, so an axis costs one VGPR pair per operand set; plain hardware min/max
+// (fminf/fmaxf would first re-canonicalise the halves taken out of the packed results); a NaN (inf - inf, 0 * inf
+// at the edge of the range) is dropped by them, which only loosens the test.
+#define RT_PKFMA(dst, planes, op) "v_pk_fma_f32 " dst ", " planes ", " op ", " op " op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+template <bool PERP>
 __device__ __forceinline__ void box2_hit_fma(const char *node, const RaySplat &R, float t_lo, float t_hi,
-                                             bool &h0, bool &h1, float &tn0, float &tn1)
+                                             float &n0, float &n1, float &f0, float &f1)
 {
-    const PlanePairs px = *(const PlanePairs *)(node + R.ox), py = *(const PlanePairs *)(node + R.oy),
-                     pz = *(const PlanePairs *)(node + R.oz);
-    const v2f xn = __builtin_elementwise_fma(px.near_, R.ix, R.nx), xf = __builtin_elementwise_fma(px.far_, R.ix, R.nx);
-    const v2f yn = __builtin_elementwise_fma(py.near_, R.iy, R.ny), yf = __builtin_elementwise_fma(py.far_, R.iy, R.ny);
-    const v2f zn = __builtin_elementwise_fma(pz.near_, R.iz, R.nz), zf = __builtin_elementwise_fma(pz.far_, R.iz, R.nz);
-    // plain hardware min/max: fminf/fmaxf would first re-canonicalise the halves taken out of the packed results
-    // (one extra v_max per operand); every input here is an FMA result or a finite bound, so there is no sNaN to quiet
-    const float n0 = hw_max3(xn.x, yn.x, hw_max(zn.x, t_lo)), f0 = hw_min3(xf.x, yf.x, hw_min(zf.x, t_hi));
-    const float n1 = hw_max3(xn.y, yn.y, hw_max(zn.y, t_lo)), f1 = hw_min3(xf.y, yf.y, hw_min(zf.y, t_hi));
-    tn0 = n0; tn1 = n1;
-    h0 = n0 <= f0; h1 = n1 <= f1;
+    PlanePairs px = *(const PlanePairs *)(node + R.ox), py = *(const PlanePairs *)(node + R.oy),
+               pz = *(const PlanePairs *)(node + R.oz);
+    // two statements: the halves of the packed results can only be named through the compiler (sub-registers, no copies)
+    v2f xe = (v2f){ 0, 0 }, ye = (v2f){ 0, 0 }, ze = (v2f){ 0, 0 };
+    if (PERP)
+        asm(RT_PKFMA("%[xe]", "%[xf]", "%[rex]") RT_PKFMA("%[ye]", "%[yf]", "%[rey]") RT_PKFMA("%[ze]", "%[zf]", "%[rez]")
+            RT_PKFMA("%[xn]", "%[xn]", "%[rnx]") RT_PKFMA("%[yn]", "%[yn]", "%[rny]") RT_PKFMA("%[zn]", "%[zn]", "%[rnz]")
+            RT_PKFMA("%[xf]", "%[xf]", "%[rfx]") RT_PKFMA("%[yf]", "%[yf]", "%[rfy]") "v_pk_fma_f32 %[zf], %[zf], %[rfz], %[rfz] op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+            : [xe] "=&v"(xe), [ye] "=&v"(ye), [ze] "=&v"(ze),
+              [xn] "+v"(px.near_), [yn] "+v"(py.near_), [zn] "+v"(pz.near_),
+              [xf] "+v"(px.far_), [yf] "+v"(py.far_), [zf] "+v"(pz.far_)
+            : [rnx] "v"(R.nx), [rny] "v"(R.ny), [rnz] "v"(R.nz), [rfx] "v"(R.fx), [rfy] "v"(R.fy), [rfz] "v"(R.fz),
+              [rex] "v"(R.ex), [rey] "v"(R.ey), [rez] "v"(R.ez));
+    else
+        asm(RT_PKFMA("%[xn]", "%[xn]", "%[rnx]") RT_PKFMA("%[yn]", "%[yn]", "%[rny]") RT_PKFMA("%[zn]", "%[zn]", "%[rnz]")
+            RT_PKFMA("%[xf]", "%[xf]", "%[rfx]") RT_PKFMA("%[yf]", "%[yf]", "%[rfy]") "v_pk_fma_f32 %[zf], %[zf], %[rfz], %[rfz] op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+            : [xn] "+v"(px.near_), [yn] "+v"(py.near_), [zn] "+v"(pz.near_),
+              [xf] "+v"(px.far_), [yf] "+v"(py.far_), [zf] "+v"(pz.far_)
+            : [rnx] "v"(R.nx), [rny] "v"(R.ny), [rnz] "v"(R.nz), [rfx] "v"(R.fx), [rfy] "v"(R.fy), [rfz] "v"(R.fz));
+    asm("v_max_f32 %[n0], %[zn0], %[tlo]\n\t"
+        "v_max_f32 %[n1], %[zn1], %[tlo]\n\t"
+        "v_min_f32 %[f0], %[zf0], %[thi]\n\t"
+        "v_min_f32 %[f1], %[zf1], %[thi]\n\t"
+        "v_max3_f32 %[n0], %[xn0], %[yn0], %[n0]\n\t"
+        "v_max3_f32 %[n1], %[xn1], %[yn1], %[n1]\n\t"
+        "v_min3_f32 %[f0], %[xf0], %[yf0], %[f0]\n\t"
+        "v_min3_f32 %[f1], %[xf1], %[yf1], %[f1]"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [f0] "=&v"(f0), [f1] "=&v"(f1)
+        : [xn0] "v"(px.near_.x), [xn1] "v"(px.near_.y), [yn0] "v"(py.near_.x), [yn1] "v"(py.near_.y),
+          [zn0] "v"(pz.near_.x), [zn1] "v"(pz.near_.y), [xf0] "v"(px.far_.x), [xf1] "v"(px.far_.y),
+          [yf0] "v"(py.far_.x), [yf1] "v"(py.far_.y), [zf0] "v"(pz.far_.x), [zf1] "v"(pz.far_.y),
+          [tlo] "v"(t_lo), [thi] "v"(t_hi));
+    if (PERP)
+        asm("v_max3_f32 %[n0], %[xe0], %[ye0], %[n0]\n\t"
+            "v_max3_f32 %[n1], %[xe1], %[ye1], %[n1]\n\t"
+            "v_max_f32 %[n0], %[ze0], %[n0]\n\t"
+            "v_max_f32 %[n1], %[ze1], %[n1]"
+            : [n0] "+v"(n0), [n1] "+v"(n1)
+            : [xe0] "v"(xe.x), [xe1] "v"(xe.y), [ye0] "v"(ye.x), [ye1] "v"(ye.y), [ze0] "v"(ze.x), [ze1] "v"(ze.y));
 }
+#undef RT_PKFMA
 
 enum { KIND_BRUTE_SPHERES = 0, KIND_BVH_SPHERES = 1, KIND_BVH_TRIANGLES = 2 };
 
@@ -597,11 +713,13 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     // traversal state of the lane's current ray
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
     float best_t = T_MAX, a = 1.0f;
-    // the same six values as register pairs, made once per ray.  The empty asm keeps the compiler from
-    // re-splatting them (8 v_mov) and re-copying t_min (1 v_mov) on every traversal step.
+    // the slab test's ray operands as register pairs, made once per ray (ray_splat).  The empty asm keeps the
+    // compiler from re-copying t_min (1 v_mov) on every traversal step.
     RaySplat RS;
-    RS.ix = RS.iy = RS.iz = (v2f){ 1.0f, 1.0f }; RS.nx = RS.ny = RS.nz = (v2f){ 0.0f, 0.0f };
+    RS.nx = RS.ny = RS.nz = RS.fx = RS.fy = RS.fz = RS.ex = RS.ey = RS.ez = (v2f){ 1.0f, 0.0f };
     RS.ox = 8u; RS.oy = NODE_AXIS_BYTES + 8u; RS.oz = 2u * NODE_AXIS_BYTES + 8u;
+    RS.perp = false;
+    bool wave_perp = false;           // wave-uniform: some lane's current ray has an axis inside its cone
     float t_min_v = P.t_min;
     asm volatile("" : "+v"(t_min_v));
 
@@ -656,37 +774,27 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 });
                 if (has_ray) {                        // start the new ray at the root
                     a = dot(L.d, L.d);
-                    f3 dd = L.d;                      // guard the reciprocal against zero components
-                    if (fabsf(dd.x) < 1e-30f) dd.x = copysignf(1e-30f, dd.x);
-                    if (fabsf(dd.y) < 1e-30f) dd.y = copysignf(1e-30f, dd.y);
-                    if (fabsf(dd.z) < 1e-30f) dd.z = copysignf(1e-30f, dd.z);
-                    const f3 inv = mk(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
-                    const f3 noi = mk(-(L.o.x * inv.x), -(L.o.y * inv.y), -(L.o.z * inv.z));
-                    {
-                        RS.ix = (v2f){ inv.x, inv.x }; RS.iy = (v2f){ inv.y, inv.y }; RS.iz = (v2f){ inv.z, inv.z };
-                        RS.nx = (v2f){ noi.x, noi.x }; RS.ny = (v2f){ noi.y, noi.y }; RS.nz = (v2f){ noi.z, noi.z };
-                        // running up an axis (sign bit clear): near = lo, the pair at +8; running down: near = hi, at +0
-                        RS.ox = ((__float_as_uint(dd.x) >> 31) ^ 1u) << 3;
-                        RS.oy = NODE_AXIS_BYTES + (((__float_as_uint(dd.y) >> 31) ^ 1u) << 3);
-                        RS.oz = 2u * NODE_AXIS_BYTES + (((__float_as_uint(dd.z) >> 31) ^ 1u) << 3);
-                        asm volatile("" : "+v"(RS.ix), "+v"(RS.iy), "+v"(RS.iz), "+v"(RS.nx), "+v"(RS.ny), "+v"(RS.nz));
-                    }
+                    ray_splat(RS, L.o, L.d, a, KIND == KIND_BVH_SPHERES ? RT_CONE_SPHERES : RT_CONE_TRIANGLES);
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                 }
             }
         }
         if (__ballot(alive || has_ray) == 0ull) break;         // queue drained and nothing in flight
+        wave_perp = __ballot(RS.perp && node != DONE) != 0ull;
 
         // ---- traversal steps: every iteration is an inner-node visit for every traversing lane; hit
-        //      leaves are only queued.
+        //      leaves are only queued.  Two copies of the loop: the slab test's extra term (box2_hit_fma<true>)
+        //      runs only in a traversal phase in which some lane needs it.
+        auto traverse = [&](auto perp_tag) {
+        constexpr bool PERP = decltype(perp_tag)::value;
         for (;;) {
             if (HIST) c_wsteps += 1;
             if (node != DONE) {
                 if (HIST) c_lsteps += 1;
-                float tn0, tn1;
-                bool h0, h1;
+                float tn0, tn1, tf0, tf1;
                 const char *nd = (LDSN ? (const char *)s_scene : (const char *)bvh) + node;   // node = byte offset
-                box2_hit_fma(nd, RS, t_min_v, best_t, h0, h1, tn0, tn1);
+                box2_hit_fma<PERP>(nd, RS, t_min_v, best_t, tn0, tn1, tf0, tf1);
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
                 const uint2 refs = *(const uint2 *)(nd + NODE_REFS_OFFSET);
                 const uint32_t c0 = refs.x, c1 = refs.y;
                 const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
@@ -716,6 +824,8 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             while (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
             if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
         }
+        };
+        if (wave_perp) traverse(std::true_type{}); else traverse(std::false_type{});
     }
     finish(O, stats, s_hist, HIST);
     if (HIST) {

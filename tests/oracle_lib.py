@@ -14,7 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "librt_oracle.so")
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
-TRAV_LIST, TRAV_BVH_REF = 0, 1
+TRAV_LIST, TRAV_BVH_REF, TRAV_BRUTE = 0, 1, 2
 
 
 class V3(C.Structure):

@@ -408,3 +408,42 @@ def test_ppm_writer(tmp_path):
     assert L.orc_write_ppm(f.encode(), img.ctypes.data, 3, 2) == 0
     lines = open(f).read().split("\n")
     assert lines[:3] == ["P3", "3 2", "255"] and lines[3] == "0 1 2" and lines[8] == "15 16 17" and lines[9] == ""
+
+
+def _telephoto_oracle(frm, half_extent, nx, ny):
+    """Far camera in BasicCamera.get_ray form (camera.zig:16): unit directions, `half_extent` wide at the origin."""
+    frm = np.asarray(frm, np.float64)
+    dist = np.linalg.norm(frm)
+    w = -frm / dist
+    u = np.cross(w, [0.0, 1.0, 0.0]); u /= np.linalg.norm(u)
+    v = np.cross(u, w)
+    hw = half_extent / dist
+    hh = hw * ny / nx
+    return O.Camera(O.v3(w - hw * u - hh * v), O.v3(2 * hw * u), O.v3(2 * hh * v), O.v3(frm), 0)
+
+
+@pytest.mark.parametrize("dist", [0.0, 3.0e3, 3.0e5])
+def test_triangle_bvh_of_the_checker_equals_the_plain_loop(dist):
+    """The checker's own triangle BVH is only a speed-up: it must return what the loop over every triangle returns,
+    also with the ray origins 10^4 .. 10^6 triangle sizes away, where Moller-Trumbore's u, v carry visible rounding
+    noise and a plain slab test would cull triangles the exact test accepts (tri_box_hit tests a cone)."""
+    rng = np.random.default_rng(3)
+    n = 12
+    sph = np.zeros(n, dtype=O.SPHERE_DTYPE)
+    sph["center"] = rng.uniform(-1.2, 1.2, (n, 3))
+    sph["radius"] = rng.choice([0.1, 0.3, 0.5], n)
+    sph["kind"] = rng.integers(0, 3, n)
+    sph["albedo"] = rng.random((n, 3))
+    sph["param"] = np.where(sph["kind"] == 2, 1.5, 0.2)
+    tris = O.tessellate(sph, 9, 7)
+    w = O.World(triangles=tris, materials=sph)
+    nx, ny, spp = 48, 32, 3
+    cam = O.camera_basic() if dist == 0.0 else _telephoto_oracle((0.5 * dist, 0.4 * dist, 0.77 * dist), 2.0, nx, ny)
+    a = O.render_counter(w, cam, O.make_config(nx, ny, spp, traversal=O.TRAV_LIST))
+    b = O.render_counter(w, cam, O.make_config(nx, ny, spp, traversal=O.TRAV_BRUTE))
+    assert b[3]["rays"] > b[3]["primary_rays"]
+    assert np.array_equal(a[2], b[2]) and a[3]["rays"] == b[3]["rays"]
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert b[3]["tri_tests"] > a[3]["tri_tests"]
+    if dist < 1e4:
+        assert b[3]["tri_tests"] > 3 * a[3]["tri_tests"]              # and it is a speed-up (at 10^5 the cone spans the scene)

@@ -12,6 +12,21 @@ import oracle_lib as O
 import raytrace_amd as R
 from helpers import spheres_to_oracle, triangles_to_oracle
 
+def telephoto(frm, at, half_extent, nx, ny):
+    """Far camera in BasicCamera.get_ray form (camera.zig:16): unit directions, frustum `half_extent` wide at `at`
+    (MovableCamera's `- origin`, camera.zig:39, cancels every direction bit at these distances)."""
+    w = at - frm; dist = np.linalg.norm(w); w = w / dist
+    u = np.cross(w, [0.0, 1.0, 0.0]); u /= np.linalg.norm(u)
+    v = np.cross(u, w)
+    hw = half_extent / dist; hh = hw * ny / nx
+    ll, hz, vt = w - hw * u - hh * v, 2 * hw * u, 2 * hh * v
+    cam = R.BasicCamera()
+    for k in range(3):
+        cam._c.lower_left[k], cam._c.horizontal[k], cam._c.vertical[k], cam._c.origin[k] = ll[k], hz[k], vt[k], frm[k]
+    cam._c.subtract_origin = 0
+    return cam, O.Camera(O.v3(ll), O.v3(hz), O.v3(vt), O.v3(frm), 0)
+
+
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = R.Context(0)
@@ -38,7 +53,12 @@ for case in range(n_cases):
     b = int(rng.integers(0, spp)); e = int(rng.integers(b, spp + 1))
     kw.update(spp_begin=b, spp_end=e, spp_total=spp)
     chunk = int(rng.choice([0, 0, 1, 2, 3, R.RT_SPP_CHUNK_AUTO]))
-    if rng.random() < 0.5:
+    far = rng.random() < 0.15                # ray origins 10^3 .. 10^6 scene sizes away: the cone cull (RT_CONE_*)
+    if far:
+        dist = float(10.0 ** rng.uniform(3.0, 6.0)) * spread
+        u = rng.standard_normal(3); u /= np.linalg.norm(u); u[1] = abs(u[1]) + 0.05
+        cam, ocam = telephoto(u * dist + np.array([0.0, 0.0, -2.0]), np.array([0.0, 0.0, -2.0]), 1.5 * spread, nx, ny)
+    elif rng.random() < 0.5:
         cam, ocam = R.BasicCamera(), O.camera_basic()
     else:
         frm = (float(rng.uniform(-6, 6)), float(rng.uniform(0.2, 4)), float(rng.uniform(2, 8)))
@@ -50,14 +70,13 @@ for case in range(n_cases):
     flags = 0
     if mesh:
         tris = R.Tessellate_Spheres(s, int(rng.integers(3, 24)), int(rng.integers(2, 16)))
-        os.environ["RT_HIP_BVH_DEPTH_CAP"] = str(int(rng.choice([8, 12, 16, 24, 32])))
+        ctx.set_tuning(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])))
         ctx.upload_scene(triangles=tris, materials=s)
         w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(s))
         what = "mesh %6d tris" % len(tris)
     else:
         flags = int(rng.choice([0, 0, R.RT_FLAG_FORCE_BRUTE_FORCE if n <= 150 else 0, R.RT_FLAG_FORCE_BVH]))
-        if rng.random() < 0.2: os.environ["RT_HIP_GLOBAL_SCENE"] = "1"
-        else: os.environ.pop("RT_HIP_GLOBAL_SCENE", None)
+        ctx.set_tuning(force_global_scene=int(rng.random() < 0.2))
         ctx.set_flags(flags)
         ctx.upload_scene(s)
         w = O.World(spheres=spheres_to_oracle(s))
@@ -66,8 +85,12 @@ for case in range(n_cases):
     ctx.set_flags(0)
     ochunk = 0 if chunk == R.RT_SPP_CHUNK_AUTO else chunk
     oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, spp_chunk=ochunk, **kw))
-    err = float(np.abs(res.accum - oa).max()) if res.accum.size else 0.0
-    ok = res.rays == cnt["rays"] and np.array_equal(res.raycount, orc) and err <= 1e-3 and np.all(np.isfinite(res.accum))
+    # far cameras: the reference's arithmetic itself yields NaN radiance in some pixels (a hit normal that has lost
+    # every bit); they must be the same pixels on both sides
+    nan = np.isnan(oa)
+    same_nan = np.array_equal(np.isnan(res.accum), nan) and (far or not nan.any())
+    err = float(np.abs(res.accum - oa)[~nan].max()) if (~nan).any() else 0.0
+    ok = res.rays == cnt["rays"] and np.array_equal(res.raycount, orc) and err <= 1e-3 and same_nan and not np.isinf(res.accum).any()
     worst = max(worst, err)
     print("case %3d %-24s %-30s %3dx%-3d spp [%d,%d)/%d chunk %s depth %2d tmin %.3g: rays %8d err %.2g %s" % (
         case, what, ctx.last_kernel_name(), nx, ny, b, e, spp, "auto" if chunk == R.RT_SPP_CHUNK_AUTO else chunk, kw["max_depth"], kw["t_min"],

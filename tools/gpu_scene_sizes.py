@@ -10,8 +10,7 @@ for half in (8, 11, 12, 13, 14, 20):
     s = R.Random_Scene(half, 0)
     ctx.upload_scene(s)
     for g in (0, 1):
-        if g: os.environ["RT_HIP_GLOBAL_SCENE"] = "1"
-        else: os.environ.pop("RT_HIP_GLOBAL_SCENE", None)
+        ctx.set_tuning(force_global_scene=g)
         for _ in range(2):
             res = ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=R.RT_SPP_CHUNK_AUTO))
         print("half %2d: %4d spheres %s forced_global=%d kernel %7.2f ms %7.0f Mrays/s" % (
