@@ -28,7 +28,8 @@ enum {
     RT_E_NOMEM = -3,
     RT_E_STATE = -4,  /* e.g. render before upload */
     RT_E_IO = -5,
-    RT_E_CAP = -6     /* output capacity too small */
+    RT_E_CAP = -6,    /* output capacity too small */
+    RT_E_NCCL = -7    /* an RCCL call failed, or RCCL could not be loaded (rt_last_rccl_error) */
 };
 
 enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
@@ -103,6 +104,7 @@ int  rt_device_count(void);
 void rt_destroy(rt_ctx *ctx);
 const char *rt_strerror(int code);
 int  rt_last_hip_error(const rt_ctx *ctx);   /* hipError_t of the last failing HIP call */
+int  rt_last_rccl_error(const rt_ctx *ctx);  /* ncclResult_t of the last failing RCCL call (rt_render_multi's root ctx) */
 int  rt_set_flags(rt_ctx *ctx, uint32_t flags);
 
 /* Kernel tuning knobs (no reference counterpart; the reference has no flags at all).  Per ctx, 0 = the
@@ -180,12 +182,19 @@ int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config
 /* Single-process multi-GPU form of rt_render: the thread fan-out + join + average of render_and_write
  * (raytracer.zig:588-617) with GPUs in place of threads.  ctxs[0..n_ctx) are distinct contexts (normally one per
  * GPU) that each hold the same uploaded scene.  GPU g traces the g-th contiguous part of [spp_begin,spp_end)
- * (sizes differ by at most one, low g takes the extra) into its own sum buffer; the peers' buffers are copied to
- * ctxs[0]'s GPU (xGMI peer copies), added there in GPU order (deterministic), tonemapped and returned as in
- * rt_render.  stats: rays summed over GPUs, kernel_ms = the slowest GPU's.  Blocking.  (A job that runs one
- * process per GPU uses rt_render_device + an RCCL reduce instead: raytrace_amd/distributed.py.) */
+ * (sizes differ by at most one, low g takes the extra) into its own sum buffer.  The exchange step -- the join and
+ * sum over threads of raytracer.zig:605-617 -- is ONE RCCL reduce (ncclReduce, f32 sum, root = ctxs[0]'s GPU, over
+ * xGMI) on a communicator the library makes with ncclCommInitAll over the contexts' GPUs at the first call and keeps
+ * on ctxs[0]; RCCL is bound at run time (dlopen), RT_E_NCCL if that fails.  Contexts that SHARE a GPU (RCCL takes
+ * one rank per GPU) fall back to copying the peers' buffers to the root and adding them there in context order.
+ * Results as in rt_render (any of accum_mean, rgb8, raycount may be NULL).  stats: rays summed over GPUs, kernel_ms
+ * = the slowest GPU's.  Blocking.  (A job that runs one process per GPU uses rt_render_device + an RCCL reduce of
+ * its own instead: raytrace_amd/distributed.py.) */
 int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, const rt_config *cfg,
-                    float *accum_mean, uint8_t *rgb8, rt_stats *stats);
+                    float *accum_mean, uint8_t *rgb8, uint32_t *raycount, rt_stats *stats);
+/* RCCL smoke for machines with one GPU (no reference counterpart): a one-rank communicator on the ctx's GPU and
+ * one in-place ncclReduce of n floats, checked.  RT_E_NCCL when RCCL cannot be loaded or fails. */
+int rt_selftest_rccl(rt_ctx *ctx, uint32_t n);
 
 /* Device tonemap: mean = sum / spp_total; rgb8 = trunc(255.99*sqrt(mean)) (raytracer.zig:527,542-549).
  * d_mean and d_rgb8 may each be NULL; d_mean may alias d_accum_sum. */

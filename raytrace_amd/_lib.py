@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")   # RT_HIP_LIB: another build of the same library (dev aid)
 
-RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP = 0, -1, -2, -3, -4, -5, -6
+RT_OK, RT_E_ARG, RT_E_HIP, RT_E_NOMEM, RT_E_STATE, RT_E_IO, RT_E_CAP, RT_E_NCCL = 0, -1, -2, -3, -4, -5, -6, -7
 RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC = 0, 1, 2
 RT_SPP_CHUNK_AUTO = 0xFFFFFFFF
 RT_NOALLOC_SCRATCH_BYTES = 64 << 20
@@ -53,7 +53,7 @@ class rt_stats(C.Structure):
 
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_set_flags", "rt_set_tuning", "rt_upload_scene",
+    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_last_rccl_error", "rt_selftest_rccl", "rt_set_flags", "rt_set_tuning", "rt_upload_scene",
     "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts",
     "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
@@ -110,8 +110,12 @@ def load():
     L.rt_selftest_cbrt_grid.restype = C.c_int
     L.rt_debug_block_counts.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     L.rt_debug_block_counts.restype = C.c_int
-    L.rt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp,
+    L.rt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp,
                                   C.POINTER(rt_stats)]
+    L.rt_last_rccl_error.argtypes = [vp]
+    L.rt_last_rccl_error.restype = C.c_int
+    L.rt_selftest_rccl.argtypes = [vp, C.c_uint32]
+    L.rt_selftest_rccl.restype = C.c_int
     L.rt_render_multi.restype = C.c_int
     L.rt_render_reference_style.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), C.c_uint32, vp,
                                             C.POINTER(rt_stats)]

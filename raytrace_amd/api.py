@@ -322,6 +322,10 @@ class Context:
         self._check(rc, "rt_render_and_write")
         return _stats_tuple(st)
 
+    def selftest_rccl(self, n=4096):
+        """rt_selftest_rccl: one-rank RCCL communicator + ncclReduce on this ctx's GPU."""
+        self._check(self._L.rt_selftest_rccl(self._h, n), "rt_selftest_rccl")
+
     def selftest_cbrt_grid(self):
         """Production cbrt on all 2^24 inputs k * 2^-24; returns (values, number of inputs that took the fallback)."""
         out = np.zeros(1 << 24, np.float32)
@@ -349,9 +353,10 @@ def device_count():
     return n
 
 
-def render_multi(contexts, cam, cfg):
+def render_multi(contexts, cam, cfg, want_raycount=False):
     """rt_render_multi: one process, several GPUs (one Context each, same scene uploaded); the sample range of
-    cfg is split across them and summed on contexts[0]'s GPU.  Blocking."""
+    cfg is split across them and summed on contexts[0]'s GPU (RCCL reduce; ordered add when contexts share a GPU).
+    Blocking."""
     if not contexts:
         raise ValueError("render_multi needs at least one Context")
     L = contexts[0]._L
@@ -359,13 +364,14 @@ def render_multi(contexts, cam, cfg):
     accum = np.zeros((n, 3), np.float32)
     rgb8 = np.zeros((n, 3), np.uint8)
     st = rt_stats()
+    rc_arr = np.zeros(n, np.uint32) if want_raycount else None
     handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     rc = L.rt_render_multi(handles, len(contexts), C.byref(cam.to_abi()), C.byref(cfg), accum.ctypes.data,
-                           rgb8.ctypes.data, C.byref(st))
+                           rgb8.ctypes.data, rc_arr.ctypes.data if want_raycount else None, C.byref(st))
     if rc != 0:
         raise RtError(rc, "rt_render_multi", max(L.rt_last_hip_error(c._h) for c in contexts))
     rays, prim, ms, hist = _stats_tuple(st)
-    return RenderResult(accum, rgb8, None, rays, prim, ms, hist)
+    return RenderResult(accum, rgb8, rc_arr, rays, prim, ms, hist)
 
 
 def write_ppm_image(fname, rgb8, nx, ny):

@@ -4,6 +4,7 @@
 // There is no CPU fallback: every render entry point needs a HIP device and fails with RT_E_HIP
 // otherwise.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -43,6 +44,11 @@ struct rt_ctx {
     uint8_t     *d_rgb8 = nullptr;   size_t rgb8_cap = 0;
     float       *d_gather = nullptr; size_t gather_cap = 0;    // rt_render_multi root: peers' sum buffers
     unsigned char *noalloc_scratch = nullptr;  // this device's copy of `scratch` (rt_render_device_noalloc)
+    // rt_render_multi with this ctx as root: the RCCL communicators over the contexts' GPUs (one rank per GPU),
+    // made at the first call and reused while the device list stays the same
+    std::vector<void *> rccl_comms;
+    std::vector<int>    rccl_devices;
+    int          last_rccl = 0;                // ncclResult_t of the last failing RCCL call
 };
 
 // ---- rt_render_device_noalloc's scratch -----------------------------------------------------------------
@@ -101,6 +107,64 @@ float recip_for_div(float y)
     const float ay = y < 0 ? -y : y;
     if (!(ay >= 0x1.0p-60f && ay <= 0x1.0p60f) || (bits & 0x7fffffu) == 0x7fffffu) return std::nanf("");
     return 1.0f / y;
+}
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------
+// Only rt_render_multi with contexts on DISTINCT GPUs needs it (one rank per GPU, one reduce onto the root: the
+// path's single exchange step).  dlopen instead of a link dependency: the single-GPU entry points work on a host
+// without RCCL, and a process that already holds an RCCL (PyTorch bundles one) keeps using that copy (same SONAME).
+struct Rccl {
+    typedef int (*CommInitAll_t)(void **comms, int ndev, const int *devlist);
+    typedef int (*CommDestroy_t)(void *comm);
+    typedef int (*Reduce_t)(const void *send, void *recv, size_t count, int dtype, int op, int root, void *comm, hipStream_t st);
+    typedef int (*Group_t)(void);
+    typedef const char *(*ErrorString_t)(int);
+    CommInitAll_t CommInitAll = nullptr; CommDestroy_t CommDestroy = nullptr; Reduce_t Reduce = nullptr;
+    Group_t GroupStart = nullptr, GroupEnd = nullptr; ErrorString_t GetErrorString = nullptr;
+    bool ok = false;
+    enum { Uint32 = 3, Float32 = 7, Sum = 0 };          // ncclDataType_t / ncclRedOp_t values (rccl.h)
+};
+const Rccl &rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return x;
+        x.CommInitAll = (Rccl::CommInitAll_t)dlsym(h, "ncclCommInitAll");
+        x.CommDestroy = (Rccl::CommDestroy_t)dlsym(h, "ncclCommDestroy");
+        x.Reduce = (Rccl::Reduce_t)dlsym(h, "ncclReduce");
+        x.GroupStart = (Rccl::Group_t)dlsym(h, "ncclGroupStart");
+        x.GroupEnd = (Rccl::Group_t)dlsym(h, "ncclGroupEnd");
+        x.GetErrorString = (Rccl::ErrorString_t)dlsym(h, "ncclGetErrorString");
+        x.ok = x.CommInitAll && x.CommDestroy && x.Reduce && x.GroupStart && x.GroupEnd;
+        return x;
+    }();
+    return r;
+}
+#define RCCL_TRY(ctx, expr)                                  \
+    do {                                                     \
+        const int r__ = (expr);                              \
+        if (r__ != 0) { (ctx)->last_rccl = r__; return RT_E_NCCL; } \
+    } while (0)
+
+void drop_comms(rt_ctx *root)
+{
+    if (!root->rccl_comms.empty() && rccl().ok)
+        for (void *c : root->rccl_comms) if (c) (void)rccl().CommDestroy(c);
+    root->rccl_comms.clear(); root->rccl_devices.clear();
+}
+// communicators of `devices` (rank g = devices[g]), cached on the root ctx
+int get_comms(rt_ctx *root, const std::vector<int> &devices)
+{
+    if (!rccl().ok) return RT_E_NCCL;
+    if (root->rccl_devices == devices && root->rccl_comms.size() == devices.size()) return RT_OK;
+    drop_comms(root);
+    std::vector<void *> comms(devices.size(), nullptr);
+    RCCL_TRY(root, rccl().CommInitAll(comms.data(), (int)devices.size(), devices.data()));
+    root->rccl_comms = comms; root->rccl_devices = devices;
+    return RT_OK;
 }
 
 int check_config(const rt_config *cfg)
@@ -291,6 +355,7 @@ const char *rt_strerror(int code)
     case RT_E_NOMEM: return "out of memory";
     case RT_E_STATE: return "invalid state (no scene uploaded?)";
     case RT_E_IO: return "I/O error";
+    case RT_E_NCCL: return "RCCL call failed or RCCL could not be loaded (see rt_last_rccl_error)";
     case RT_E_CAP: return "capacity too small (output buffer, or the fixed scratch of rt_render_device_noalloc)";
     default: return "unknown error";
     }
@@ -354,6 +419,7 @@ void rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_partial); (void)hipFree(ctx->d_raycount); (void)hipFree(ctx->d_mean); (void)hipFree(ctx->d_rgb8);
     (void)hipFree(ctx->d_gather);
+    drop_comms(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -361,6 +427,7 @@ void rt_destroy(rt_ctx *ctx)
 }
 
 int rt_last_hip_error(const rt_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+int rt_last_rccl_error(const rt_ctx *ctx) { return ctx ? ctx->last_rccl : 0; }
 
 int rt_set_flags(rt_ctx *ctx, uint32_t flags)
 {
@@ -619,18 +686,27 @@ int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config
 }
 
 int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, const rt_config *cfg,
-                    float *accum_mean, uint8_t *rgb8, rt_stats *stats)
+                    float *accum_mean, uint8_t *rgb8, uint32_t *raycount, rt_stats *stats)
 {
+    return guarded([&]() -> int {
     if (!ctxs || n_ctx == 0 || n_ctx > 64 || !cam) return RT_E_ARG;
     int rc = check_config(cfg);
     if (rc != RT_OK) return rc;
+    bool distinct = n_ctx > 1;            // every context on a GPU of its own: the exchange step is an RCCL reduce
+    std::vector<int> devices(n_ctx);
     for (uint32_t g = 0; g < n_ctx; ++g) {
         if (!ctxs[g]) return RT_E_ARG;
-        for (uint32_t k = 0; k < g; ++k) if (ctxs[k] == ctxs[g]) return RT_E_ARG;
+        for (uint32_t k = 0; k < g; ++k) {
+            if (ctxs[k] == ctxs[g]) return RT_E_ARG;
+            if (ctxs[k]->device == ctxs[g]->device) distinct = false;
+        }
         if (ctxs[g]->n_sph == 0 && ctxs[g]->n_tri == 0) return RT_E_STATE;
+        devices[g] = ctxs[g]->device;
     }
     rt_ctx *root = ctxs[0];
     const size_t npix = (size_t)cfg->nx * cfg->ny, nfl = npix * 3;
+    const size_t gather_words = nfl + (raycount ? npix : 0);      // per peer: its sums, then its ray counts
+    if (distinct && (rc = get_comms(root, devices)) != RT_OK) return rc;
     // contiguous sample ranges, sizes differ by at most one, low indices take the extra (raytracer.zig:594-600
     // hands every thread its own samples; here GPU g owns global sample indices [b_g, e_g))
     const uint32_t span = cfg->spp_end - cfg->spp_begin, base = span / n_ctx, extra = span % n_ctx;
@@ -640,24 +716,47 @@ int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, c
         HIP_TRY(c, hipSetDevice(c->device));
         if ((rc = ensure(c, c->d_accum, c->accum_cap, nfl)) != RT_OK) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, nfl * sizeof(float), c->stream));
+        if (raycount) {
+            if ((rc = ensure(c, c->d_raycount, c->raycount_cap, npix)) != RT_OK) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->d_raycount, 0, npix * sizeof(uint32_t), c->stream));
+        }
         rt_config sub = *cfg;
         sub.spp_begin = cfg->spp_begin + g * base + (g < extra ? g : extra);
         sub.spp_end = sub.spp_begin + base + (g < extra ? 1 : 0);
-        if ((rc = enqueue_trace(c, cam, &sub, c->d_accum, nullptr, c->stream)) != RT_OK) return rc;
+        if ((rc = enqueue_trace(c, cam, &sub, c->d_accum, raycount ? c->d_raycount : nullptr, c->stream)) != RT_OK) return rc;
     }
-    // 2. the path's one exchange step: peers' buffers travel to the root GPU (xGMI peer copies, all links at once)
+    // 2. the path's one exchange step (the reference's join + sum over threads, raytracer.zig:605-617)
     HIP_TRY(root, hipSetDevice(root->device));
-    if (n_ctx > 1 && (rc = ensure(root, root->d_gather, root->gather_cap, nfl * (n_ctx - 1))) != RT_OK) return rc;
     if ((rc = ensure(root, root->d_mean, root->mean_cap, nfl)) != RT_OK) return rc;
     if ((rc = ensure(root, root->d_rgb8, root->rgb8_cap, nfl)) != RT_OK) return rc;
-    for (uint32_t g = 1; g < n_ctx; ++g) {
-        rt_ctx *c = ctxs[g];
-        HIP_TRY(c, hipSetDevice(c->device));
-        float *dst = root->d_gather + (size_t)(g - 1) * nfl;
-        if (c->device == root->device)
-            HIP_TRY(c, hipMemcpyAsync(dst, c->d_accum, nfl * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        else
-            HIP_TRY(c, hipMemcpyPeerAsync(dst, root->device, c->d_accum, c->device, nfl * sizeof(float), c->stream));
+    if (distinct) {
+        // one rank per GPU, ncclReduce(sum) onto rank 0 over xGMI, each on its ctx's stream behind the trace kernel
+        RCCL_TRY(root, rccl().GroupStart());
+        for (uint32_t g = 0; g < n_ctx; ++g) {
+            rt_ctx *c = ctxs[g];
+            HIP_TRY(c, hipSetDevice(c->device));
+            int r = rccl().Reduce(c->d_accum, c->d_accum, nfl, Rccl::Float32, Rccl::Sum, 0, root->rccl_comms[g], c->stream);
+            if (r == 0 && raycount)
+                r = rccl().Reduce(c->d_raycount, c->d_raycount, npix, Rccl::Uint32, Rccl::Sum, 0, root->rccl_comms[g], c->stream);
+            if (r != 0) { (void)rccl().GroupEnd(); root->last_rccl = r; return RT_E_NCCL; }
+        }
+        RCCL_TRY(root, rccl().GroupEnd());
+    } else if (n_ctx > 1) {
+        // contexts that share a GPU (RCCL takes one rank per GPU): the peers' buffers are copied next to the root's
+        // and added there in context order (deterministic)
+        if ((rc = ensure(root, root->d_gather, root->gather_cap, gather_words * (n_ctx - 1))) != RT_OK) return rc;
+        for (uint32_t g = 1; g < n_ctx; ++g) {
+            rt_ctx *c = ctxs[g];
+            HIP_TRY(c, hipSetDevice(c->device));
+            float *dst = root->d_gather + (size_t)(g - 1) * gather_words;
+            const bool same = c->device == root->device;
+            if (same) HIP_TRY(c, hipMemcpyAsync(dst, c->d_accum, nfl * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            else HIP_TRY(c, hipMemcpyPeerAsync(dst, root->device, c->d_accum, c->device, nfl * sizeof(float), c->stream));
+            if (raycount) {
+                if (same) HIP_TRY(c, hipMemcpyAsync(dst + nfl, c->d_raycount, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+                else HIP_TRY(c, hipMemcpyPeerAsync(dst + nfl, root->device, c->d_raycount, c->device, npix * sizeof(uint32_t), c->stream));
+            }
+        }
     }
     rt_stats total; std::memset(&total, 0, sizeof total);
     for (uint32_t g = 0; g < n_ctx; ++g) {          // join (raytracer.zig:605-607)
@@ -669,17 +768,49 @@ int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, c
         if (one.kernel_ms > total.kernel_ms) total.kernel_ms = one.kernel_ms;     // GPUs run side by side
         for (int k = 0; k < 20; ++k) total.rays_by_depth[k] += one.rays_by_depth[k];
     }
-    // 3. root adds the peers' sums in GPU order (deterministic), tonemaps, hands the images back
+    // 3. root tonemaps and hands the images back
     HIP_TRY(root, hipSetDevice(root->device));
     hipStream_t st = root->stream;
-    if (n_ctx > 1)
-        HIP_TRY(root, rt_launch_reduce_chunks(root->d_accum, root->d_gather, (uint32_t)npix, n_ctx - 1, (uint32_t)nfl, st));
+    if (!distinct && n_ctx > 1) {
+        HIP_TRY(root, rt_launch_reduce_chunks(root->d_accum, root->d_gather, (uint32_t)npix, n_ctx - 1, gather_words, st));
+        if (raycount)
+            HIP_TRY(root, rt_launch_u32_add_planes(root->d_raycount, (const uint32_t *)(root->d_gather + nfl), (uint32_t)npix,
+                                                   n_ctx - 1, gather_words, st));
+    }
     HIP_TRY(root, rt_launch_tonemap(root->d_accum, (uint32_t)npix, cfg->spp_total, root->d_mean, root->d_rgb8, st));
     if (accum_mean) HIP_TRY(root, hipMemcpyAsync(accum_mean, root->d_mean, nfl * sizeof(float), hipMemcpyDeviceToHost, st));
     if (rgb8) HIP_TRY(root, hipMemcpyAsync(rgb8, root->d_rgb8, nfl, hipMemcpyDeviceToHost, st));
+    if (raycount) HIP_TRY(root, hipMemcpyAsync(raycount, root->d_raycount, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(root, hipStreamSynchronize(st));
     if (stats) *stats = total;
     return RT_OK;
+    });
+}
+
+// RCCL smoke: a communicator over this ctx's GPU alone (one rank), one in-place ncclReduce(sum) of n floats, checked.
+// What a one-GPU machine can exercise of rt_render_multi's exchange step.
+int rt_selftest_rccl(rt_ctx *ctx, uint32_t n)
+{
+    return guarded([&]() -> int {
+    if (!ctx || n == 0 || n > (1u << 24)) return RT_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = get_comms(ctx, std::vector<int>{ ctx->device });
+    if (rc != RT_OK) return rc;
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, (size_t)n * sizeof(float)));
+    std::vector<float> h(n), back(n);
+    for (uint32_t k = 0; k < n; ++k) h[k] = (float)(k % 1000) * 0.25f;
+    hipError_t e = hipMemcpyAsync(d, h.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    int r = 0;
+    if (e == hipSuccess) r = rccl().Reduce(d, d, n, Rccl::Float32, Rccl::Sum, 0, ctx->rccl_comms[0], ctx->stream);
+    if (e == hipSuccess && r == 0) e = hipMemcpyAsync(back.data(), d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (r != 0) { ctx->last_rccl = r; return RT_E_NCCL; }
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return RT_E_HIP; }
+    for (uint32_t k = 0; k < n; ++k) if (back[k] != h[k]) return RT_E_STATE;     // a one-rank sum is the identity
+    return RT_OK;
+    });
 }
 
 int rt_render_and_write(rt_ctx *ctx, const char *fname, const rt_camera *cam, const rt_config *cfg, rt_stats *stats)

@@ -26,13 +26,15 @@ struct TraceParams {
     uint32_t keep_traversing;               // BVH kernels: leave the traversal loop when fewer lanes than this traverse
 };
 
-// Device scene.  16-byte records so one scalar/vector load fetches a whole record.
-//   spheres:   geom[i]   = { cx, cy, cz, radius*radius }   (all the brute-force inner loop reads)
-//              aux[i]    = { radius, bits(kind), param, 0 } (material i = sphere i)
-//              albedo[i] = { r, g, b, 0 }
+// Device scene (made at upload, rt_api.cpp rt_upload_scene).  16-byte records so one scalar/vector load fetches a whole record.
+//   spheres:   geom[i]       = { cx, cy, cz, radius*radius }   (all the intersection code reads)
+//              aux[i]        = { radius, bits(kind), param, RN(1/radius) or NaN (no fast reciprocal: IEEE divide) }
+//                              (material i = sphere i)
+//              albedo[2i]    = { r, g, b, schlick r0^2 },  albedo[2i+1] = { 1/index, 0, 0, 0 }   (TWO records per material)
 //   triangles: tri[3i+0] = { v0.xyz, bits(material) }, tri[3i+1] = { v1.xyz, 0 }, tri[3i+2] = { v2.xyz, 0 }
-//              aux/albedo are the material table (aux.x unused)
-//   bvh:       4 float4 per node (rt_bvh.hpp Node), root = node 0
+//              aux/albedo are the material table (aux.x and aux.w unused)
+//   bvh:       RT_NODE_BYTES (80) per node = five float4, root = node 0.  The host builder's 64-byte node (rt_bvh.hpp Node)
+//              is converted to this layout at upload:
 // Device BVH node, RT_NODE_BYTES = 80: per axis (x, y, z; 24 bytes each) the planes of the two child boxes as
 // {hi0, hi1, lo0, lo1, hi0, hi1} -- a lane reads 16 bytes at +8 (ray runs up the axis) or +0 (down) and gets
 // {near0, near1, far0, far1} without a min/max --, then the two child refs at byte 72: bit 31 set = primitive index,
@@ -68,6 +70,9 @@ const char *rt_trace_kernel_name(TraceKernel which);
 
 hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,
                                    size_t plane_stride, hipStream_t stream);
+
+hipError_t rt_launch_u32_add_planes(uint32_t *dst, const uint32_t *planes, uint32_t n, uint32_t n_planes,
+                                    size_t plane_stride, hipStream_t stream);
 
 hipError_t rt_launch_tonemap(const float *accum_sum, uint32_t n_pixels, uint32_t spp_total,
                              float *mean, uint8_t *rgb8, hipStream_t stream);

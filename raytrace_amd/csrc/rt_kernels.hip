@@ -845,6 +845,17 @@ __global__ __launch_bounds__(256) void rt_reduce_chunks_kernel(float *accum, con
     accum[k] += acc;
 }
 
+// rt_render_multi on a shared GPU: ray counts of the peers added to the root's
+__global__ __launch_bounds__(256) void rt_u32_add_planes_kernel(uint32_t *dst, const uint32_t *planes, uint32_t n,
+                                                                uint32_t n_planes, size_t plane_stride)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t acc = dst[k];
+    for (uint32_t c = 0; c < n_planes; ++c) acc += planes[c * plane_stride + k];
+    dst[k] = acc;
+}
+
 // mean = sum / spp_total (raytracer.zig:542), sqrt gamma (:545-549), 255.99 truncation (:527)
 __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float *accum_sum, uint32_t n_values, float spp_total,
                                                          float *mean, uint8_t *rgb8)
@@ -992,6 +1003,14 @@ hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint3
     if (n == 0 || n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(rt_reduce_chunks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream,
                        accum_sum, partial, n, n_chunks, plane_stride);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_u32_add_planes(uint32_t *dst, const uint32_t *planes, uint32_t n, uint32_t n_planes,
+                                    size_t plane_stride, hipStream_t stream)
+{
+    if (n == 0 || n_planes == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_u32_add_planes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, dst, planes, n, n_planes, plane_stride);
     return hipGetLastError();
 }
 

@@ -413,6 +413,41 @@ def test_c5_resolution_3840x2160_sampled_pixels(gpu_ctx):
     assert res.primary_rays == nx * ny * 4
 
 
+def test_c5_full_size_3840x2160_1024spp_split_over_two_contexts(gpu_ctx):
+    """configs[4] at FULL size: 3840x2160, 1024 spp, the samples split over two contexts by rt_render_multi
+    (raytracer.zig:594-617 with GPUs for threads; on this one-GPU box both contexts sit on device 0, so the
+    exchange step is the shared-GPU ordered add -- the RCCL reduce needs distinct GPUs).  8.5 G primary rays;
+    the oracle renders 2 500 random pixels at all 1024 samples: ray counts exact, linear mean within 1e-3."""
+    nx, ny, spp = 3840, 2160, 1024
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    with R.Context(0) as other:
+        other.upload_scene(s)
+        res = R.render_multi([gpu_ctx, other], cam, R.make_config(nx, ny, spp, spp_chunk=R.RT_SPP_CHUNK_AUTO),
+                             want_raycount=True)
+    rng = np.random.default_rng(55)
+    pix = np.unique(np.concatenate([rng.integers(0, nx * ny, 2500), [0, nx - 1, nx * ny - nx, nx * ny - 1]])).astype(np.uint32)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, o8, orc, _ = O.render_counter(w, ocam, O.make_config(nx, ny, spp), pixels=pix)
+    assert np.array_equal(res.raycount[pix], orc)
+    err = float(np.abs(res.accum[pix] - oa).max())
+    assert err <= TOL_ACCUM, err
+    assert psnr_u8(res.rgb8[pix], o8) >= MIN_PSNR
+    assert res.primary_rays == nx * ny * spp and res.rays == int(res.raycount.astype(np.uint64).sum())
+    assert res.raycount.min() >= spp and res.raycount.max() <= spp * 18
+    assert np.all(np.isfinite(res.accum)) and res.accum.min() >= 0 and res.accum.max() <= 1.0 + 1e-5
+    print("C5 4K/1024spp over 2 contexts: %d rays, slowest context %.0f ms, sampled max err %.3g"
+          % (res.rays, res.kernel_ms, err))
+
+
+def test_rccl_single_rank_smoke(gpu_ctx):
+    """What one GPU can exercise of rt_render_multi's RCCL exchange step: the library loads RCCL, makes a one-rank
+    communicator on the ctx's GPU (ncclCommInitAll) and runs an in-place ncclReduce(sum) on the ctx's stream.
+    The N > 1 reduce itself needs distinct GPUs (the driver's 8-GPU node)."""
+    gpu_ctx.selftest_rccl(1 << 16)
+    gpu_ctx.selftest_rccl(3)          # the communicator is cached on the ctx
+
+
 # ---- sharding properties (SURVEY 8(e)) -----------------------------------------------------------------
 def test_spp_ranges_sum_to_the_whole(gpu_ctx):
     nx, ny, spp = 160, 90, 12
@@ -642,23 +677,33 @@ def test_render_device_and_tonemap_device(gpu_ctx):
 
 def test_reference_style_u8_mean_of_images(gpu_ctx):
     """render_and_write's merge (raytracer.zig:594-617, quirk Q4): N whole-image renders keyed i*123, each
-    quantised to u8, integer mean.  Checker: the oracle rendered once per seed + numpy integer mean."""
-    nx, ny, spp, n_images = 64, 36, 3, 5
+    quantised to u8 (:527), then the per-channel INTEGER mean (:610-617).  Checker: the oracle in the same mode --
+    counter RNG keyed i*123, one render per image, numpy integer sum and truncating divide.  Byte work, so the bar is
+    equality: every channel must be identical, except where one of the N linear values sits within 1e-6 (relative) of a
+    quantisation threshold -- there the GPU's running-product rounding (~1e-7) may land on the other side, one image's
+    byte moves by one and the mean by at most one."""
+    nx, ny, spp, n_images = 96, 54, 3, 5
     s, cam, ocam = _scene("book", nx, ny)
     gpu_ctx.upload_scene(s)
     img, (rays, prim, _ms, _) = gpu_ctx.render_reference_style(cam, R.make_config(nx, ny, spp, seed=99), n_images)
     w = O.World(spheres=spheres_to_oracle(s))
     acc = np.zeros((nx * ny, 3), np.uint32)
+    near_threshold = np.zeros((nx * ny, 3), bool)
     orays = 0
     for i in range(n_images):
-        _, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, seed=i * 123))
+        oa, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, seed=i * 123))
+        q = (np.float32(255.99) * np.sqrt(oa)).astype(np.float64)         # f32, as raytracer.zig:527 computes it
+        near_threshold |= np.abs(q - np.round(q)) <= 1e-6 * np.maximum(q, 1.0) * 0.5 + 1e-6 * 255.99
+        assert np.array_equal(o8, np.clip(q.astype(np.int64), 0, 255).astype(np.uint8))     # the oracle's own tonemap
         acc += o8
         orays += cnt["rays"]
     ref = (acc // n_images).astype(np.uint8)
     assert rays == orays and prim == nx * ny * spp * n_images
-    assert psnr_u8(img, ref) >= MIN_PSNR
+    assert np.array_equal(img[~near_threshold], ref[~near_threshold])
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+    assert near_threshold.mean() < 0.01
     lin = gpu_ctx.render(cam, R.make_config(nx, ny, spp * n_images, seed=0)).rgb8   # the linear-mean image differs (Q4)
-    assert img.shape == lin.shape
+    assert img.shape == lin.shape and not np.array_equal(img, lin)
 
 
 def test_render_and_write_ppm(gpu_ctx, tmp_path):
