@@ -32,6 +32,8 @@ WORKLOADS = {
     "c3": ("book", 1920, 1080, 100, 16, "opcounts_c3.json"),
     "c2": ("two", 1920, 1080, 100, 16, "opcounts_c2.json"),
     "c1": ("book", 400, 225, 10, 10, "opcounts_c1.json"),
+    # BASELINE configs[3]: the book scene's spheres tessellated as the reference's raster preview does (main.zig:128-138)
+    "c4": ("mesh", 1920, 1080, 256, 16, "opcounts_c4.json"),
     # BASELINE configs[4]: STRONG scaling -- the 1024 samples are split over the ranks.  flops/ray: the C3 figure
     # (same scene, camera and depth cap; only the pixel grid is finer)
     "c5": ("book", 3840, 2160, 1024, 16, "opcounts_c3.json"),
@@ -41,24 +43,74 @@ WORKLOAD_DESC = {
     "c3": "book final scene (Random_Scene(11), sfc64 seed 0) 1920x1080 100spp depth16",
     "c2": "single sphere + ground lambertian 1920x1080 100spp depth16",
     "c1": "book final scene 400x225 10spp depth10",
+    "c4": "procedural triangle-mesh scene (book scene tessellated, 285 520 triangles) 1920x1080 256spp depth16",
     "c5": "book final scene 3840x2160 1024spp depth16, samples split over the GPUs",
 }
 
 
-def cpu_baseline(workload, budget_threads):
-    """Reference-style CPU render (oracle: threads x whole image x 1 spp each, sfc64 seeds i*123,
-    reference BVH) on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    """Hardware threads this process may use: the scheduler affinity, capped by the GPU box's CPU share per GPU
+    (16: os.cpu_count() there reports the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def build_native_oracle():
+    """The timed build of the CPU port: -O3 -march=native, no op counters in the inner loops (oracle/Makefile,
+    target native), compiled on THIS host (the checker's prebuilt generic -O2 library is the fallback)."""
+    import subprocess
+    out = os.path.join(ROOT, "oracle", "_native", "librt_oracle_native.so")
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native"], check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if os.path.exists(out):
+            return out, "-O3 -march=native, lean counters, built on this host"
+    except Exception:
+        pass
+    return None, "prebuilt generic -O2 build with op counters (native build failed)"
+
+
+def cpu_baseline(workload, threads):
+    """Reference-style CPU render (oracle: threads x whole image x 1 spp each, sfc64 seeds i*123, reference BVH --
+    the restatement of render_and_write, raytracer.zig:580-633) on a bounded sample of the same workload, timed
+    wall-clock around spawn -> join like raytracer.zig:584-608."""
+    lib, how = build_native_oracle()
+    if lib:
+        os.environ["RT_ORACLE_LIB"] = lib
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     scene, nx, ny, _spp, depth, _ = WORKLOADS[workload]
-    sph = O.random_scene(11, 0) if scene == "book" else O.two_sphere_scene()
-    cam = O.book_camera(nx, ny) if scene == "book" else O.camera_basic()
-    w = O.World(spheres=sph)
-    cfg = O.make_config(nx, ny, 1, max_depth=depth, traversal=O.TRAV_BVH_REF if scene == "book" else O.TRAV_LIST)
-    _, cnt, sec = O.render_reference_style(w, cam, cfg, budget_threads, 1)
-    return {"value": cnt["rays"] / sec / 1e6, "unit": "Mrays/s", "cores": budget_threads, "kind": "port",
-            "sample": "%dx%d, 1 spp per thread x %d threads (render_and_write restatement, sfc64 seeds i*123, "
-                      "reference BVH), %.1f s" % (nx, ny, budget_threads, sec)}
+    if scene == "mesh":
+        sph = O.random_scene(11, 0)
+        w = O.World(triangles=O.tessellate(sph, 0, 0), materials=sph)
+        cam, trav, what = O.book_camera(nx, ny), O.TRAV_LIST, "the checker's triangle BVH"
+    elif scene == "book":
+        w, cam, trav, what = O.World(spheres=O.random_scene(11, 0)), O.book_camera(nx, ny), O.TRAV_BVH_REF, "reference BVH"
+    else:
+        w, cam, trav, what = O.World(spheres=O.two_sphere_scene()), O.camera_basic(), O.TRAV_LIST, "list traversal"
+    spp_thread = {"two": 40, "book": 3, "mesh": 2}[scene]        # 10-30 s of CPU work on 16 threads
+    if nx * ny < 1000000:
+        spp_thread *= 8
+    cfg = O.make_config(nx, ny, spp_thread, max_depth=depth, traversal=trav)
+    _, cnt, sec = O.render_reference_style(w, cam, cfg, threads, spp_thread)
+    return {"value": cnt["rays"] / sec / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model(), "build": how,
+            "sample": "%dx%d, %d spp per thread x %d threads (render_and_write restatement, sfc64 seeds i*123, %s), "
+                      "%.1f s" % (nx, ny, spp_thread, threads, what, sec)}
 
 
 def main():
@@ -68,6 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-eighth", action="store_true", help="skip the 32-CU (1/8 GPU) leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -96,10 +149,16 @@ def main():
             dist.init_process_group(backend)
 
     scene, nx, ny, spp, depth, opfile = WORKLOADS[args.workload]
-    spheres = R.Random_Scene(11, 0) if scene == "book" else R.Two_Sphere_Scene()
-    cam = R.book_camera(nx, ny) if scene == "book" else R.BasicCamera()
+    spheres = R.Two_Sphere_Scene() if scene == "two" else R.Random_Scene(11, 0)
+    cam = R.BasicCamera() if scene == "two" else R.book_camera(nx, ny)
     ctx = R.Context(device_index)
-    ctx.upload_scene(spheres)
+    n_tri = 0
+    if scene == "mesh":
+        tris = R.Tessellate_Spheres(spheres, 0, 0)
+        n_tri = len(tris)
+        ctx.upload_scene(triangles=tris, materials=spheres)
+    else:
+        ctx.upload_scene(spheres)
     from raytrace_amd.distributed import HipRangeRenderer, render_sample_sharded
     npix = nx * ny
     renderer = HipRangeRenderer(ctx, cam, nx, ny, max_depth=depth, seed=1)
@@ -178,21 +237,43 @@ def main():
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_DESC[args.workload], "n_spheres": len(spheres), "nx": nx, "ny": ny,
+            "config": {"workload": WORKLOAD_DESC[args.workload], "n_spheres": len(spheres), "n_triangles": n_tri,
+                       "upload_ms": ctx.upload_ms(), "nx": nx, "ny": ny,
                        "spp_per_gpu": spp_total / world, "spp_total": spp_total, "max_depth": depth, "seed": 1,
                        "rays_per_step": rays_all, "reduce_ms_rank0": float(np.mean(reduce_ms)) if world > 1 else 0.0,
                        "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "executed": executed,
+                         "scope": "rank 0's GPU" if world > 1 else "the GPU",
                          "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
                          "kernel_mrays_per_s": rays_per_step[0] / (k_ms * 1e-3) / 1e6,
-                         "note": "FP32 vector roofline (not HBM/MFMA): algorithmic flops per ray are those of the "
-                                 "reference's own BVH traversal on this config (tests/golden/%s, SURVEY 8(d))" % opfile},
+                         "note": "FP32 vector roofline (not HBM/MFMA). achieved = ALGORITHMIC flops: per ray those of the "
+                                 "reference's own traversal on this config (tests/golden/%s, SURVEY 8(d); C4: the checker's "
+                                 "plain BVH, the reference has no triangle code) -- a throughput normalised to the reference's "
+                                 "work, not executed instructions; the hardware-counted figure is `executed`" % opfile},
         }
+        if world == 1 and not args.no_one_eighth:
+            # the "@1/8 GPU" half of BASELINE.json's metric: the same step on 32 of the 256 CUs (a CU-masked stream,
+            # 4 CUs on each XCD), against 1/8 of the FP32 vector peak
+            ctx.set_cu_mask(32)
+            ms8 = []
+            for k in range(1 + min(3, args.steps)):
+                acc8 = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")
+                cfg8 = R.make_config(nx, ny, spp, max_depth=depth, seed=1, spp_chunk=R.RT_SPP_CHUNK_AUTO)
+                r8, _, m8, _ = ctx.render_device(cam, cfg8, acc8.data_ptr(), 0, 0, want_stats=True)
+                if k:
+                    ms8.append(m8)
+            ctx.set_cu_mask(None)
+            k8 = float(np.mean(ms8))
+            a8 = r8 * fpr / (k8 * 1e-3) / 1e12
+            out["roofline_one_eighth_gpu"] = {"cus": 32, "peak": PEAK_FP32_TFLOPS / 8, "unit": "TFLOP/s", "achieved": a8,
+                                              "frac": a8 / (PEAK_FP32_TFLOPS / 8), "kernel_ms": k8,
+                                              "mrays_per_s": r8 / (k8 * 1e-3) / 1e6,
+                                              "note": "same workload and kernel on a CU-masked stream: 32 CUs, 4 on each XCD"}
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            threads = args.cpu_threads or host_threads()
             out["cpu_baseline"] = cpu_baseline(args.workload, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -119,6 +119,13 @@ typedef struct {
 } rt_tuning;
 int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaults */
 
+/* Restrict the ctx's own stream to a subset of the GPU's compute units (hipExtStreamCreateWithCUMask; bit i of
+ * mask[] = CU i; on MI355X bit i lies on XCD i % 8) and size the persistent grid for that many CUs; NULL restores
+ * the whole GPU.  No reference counterpart: it produces the "@1/8 GPU" figure of BASELINE.json's metric (32 CUs,
+ * 19.66 TFLOP/s of FP32 vector peak).  Renders on a caller-supplied stream are not affected.  Note (ROCm 7.2): a
+ * mask that leaves an XCD without any CU crashes inside the HIP runtime; keep at least one CU per XCD. */
+int  rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words);
+
 /* ---- scene upload: the `world: Hittable` argument of Render (raytracer.zig:517) ------------- */
 /* Exactly one of spheres / triangles per scene; `materials` (kind, r, g, b, param) is required with
  * triangles.  Replaces the reference's CPU acceleration build (build_BVH, raytracer.zig:279-376): the
@@ -129,6 +136,9 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *
 /* What the last upload built (any pointer may be NULL). */
 int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
                   uint32_t *bvh_depth);
+/* Wall time of the last rt_upload_scene: repacking + BVH build + validation on the host, and device allocation +
+ * copies (the role of the timings build_BVH prints, raytracer.zig:301-308,690). */
+int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms);
 /* Profiling aid, no reference counterpart: after a render with RT_FLAG_DEPTH_HISTOGRAM on a BVH scene,
  * out = { wave traversal steps, lane traversal steps, wave exact-test iterations, lane exact-test
  * iterations, wave shading passes, lanes shaded } -- lane/(64*wave) is the fill of each phase. */
@@ -171,6 +181,19 @@ int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int rt_render_device_noalloc(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg,
                              float *d_accum_sum, uint32_t *d_raycount, void *stream);
+
+/* Progressive form for an interactive caller -- the GUI's "Trace" button (main.zig:342-345 -> start_trace,
+ * main.zig:307-318), which today blocks the UI thread until the PPM is written; shaped like the reference's unused
+ * compute slot (compute.zig:123-207: dispatch, then poll until the result can be mapped).  No callbacks:
+ *     rt_progressive_begin(ctx, &cam, &cfg, n_passes);
+ *     do { rc = rt_progressive_step(ctx, rgb8, NULL, &spp_done, NULL); show(rgb8); } while (rc == RT_PROGRESS_MORE);
+ * The samples [spp_begin,spp_end) are rendered in n_passes contiguous parts into one device SUM buffer owned by the
+ * ctx; each step renders one part, tonemaps the mean over the samples so far (the last step divides by spp_total,
+ * so its image IS rt_render's with spp_chunk = the pass size) and copies it to the host.  Returns RT_PROGRESS_MORE
+ * while passes remain, RT_OK after the last one, a negative code on error (which ends the render). */
+#define RT_PROGRESS_MORE 1
+int rt_progressive_begin(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_passes);
+int rt_progressive_step(rt_ctx *ctx, uint8_t *rgb8, float *accum_mean, uint32_t *spp_done, rt_stats *stats);
 
 /* The reference's own merge (quirk Q4), for A/B against a Zig render: n_images whole-image renders of
  * cfg->spp_total samples each, image i keyed with seed i*123 (raytracer.zig:600; cfg->seed is ignored), each

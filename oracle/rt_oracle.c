@@ -9,6 +9,15 @@
  */
 #include "rt_oracle.h"
 
+/* Counters inside the intersection loops (sphere / box / triangle tests).  The parity build keeps them (they feed
+ * tests/golden/opcounts_*.json); the build bench.py TIMES as the CPU baseline (make native: -O3 -march=native
+ * -DORC_LEAN_COUNTERS) leaves them out so that the baseline is not slowed by bookkeeping.  Ray counts stay. */
+#ifdef ORC_LEAN_COUNTERS
+#define ORC_COUNT(x) ((void)0)
+#else
+#define ORC_COUNT(x) ((x)++)
+#endif
+
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
@@ -549,7 +558,7 @@ typedef struct {
 
 static int sphere_hit_rec(const hit_ctx *c, uint32_t idx, orc_v3 ro, orc_v3 rd, float t_min, float t_max, hit_rec *rec)
 {
-    c->cnt->sphere_tests++;
+    ORC_COUNT(c->cnt->sphere_tests);
     if (orc_sphere_hit(&c->w->sph[idx], ro, rd, t_min, t_max, &rec->t, &rec->p, &rec->normal)) {
         rec->prim = idx; rec->material = idx;
         return 1;
@@ -572,7 +581,7 @@ static int list_hit(const hit_ctx *c, orc_v3 ro, orc_v3 rd, float t_min, float t
 /* TreeNode.hit / BranchNode.hit / LeafNode.hit, raytracer.zig:191-267 */
 static int node_hit(const hit_ctx *c, const ref_node *n, orc_v3 ro, orc_v3 rd, float t_min, float t_max, hit_rec *out)
 {
-    c->cnt->aabb_tests++;
+    ORC_COUNT(c->cnt->aabb_tests);
     if (!aabb_hit(&n->bbox, ro, rd, t_min, t_max)) return 0;
     if (n->is_leaf) {
         hit_rec temp_rec; int hit_anything = 0; float closest_so_far = t_max;
@@ -602,12 +611,13 @@ static void tri_traverse(const hit_ctx *c, orc_v3 ro, orc_v3 rd, float t_min, hi
         const tri_node *n = &w->tnodes[stack[--sp]];
         /* allow ties through: a later-visited, lower-index triangle at equal t must still be seen */
         float tmax = *have ? best->t : FLT_MAX;
+        ORC_COUNT(c->cnt->aabb_tests);
         if (!tri_box_hit(n, ro, rd, t_min, tmax)) continue;
         if (n->count) {
             for (uint32_t k = 0; k < n->count; k++) {
                 uint32_t ti = w->tri_order[n->first + k];
                 hit_rec rec;
-                c->cnt->tri_tests++;
+                ORC_COUNT(c->cnt->tri_tests);
                 if (orc_triangle_hit(&w->tri[ti], ro, rd, t_min, FLT_MAX, &rec.t, &rec.p, &rec.normal)) {
                     rec.prim = w->n_sph + ti; rec.material = w->tri[ti].material;
                     if (!*have || rec.t < best->t || (rec.t == best->t && rec.prim < best->prim)) {
@@ -634,7 +644,7 @@ static int world_hit(const hit_ctx *c, orc_v3 ro, orc_v3 rd, float t_min, float 
     if (c->w->n_tri && c->traversal == ORC_TRAV_BRUTE) {
         for (uint32_t ti = 0; ti < c->w->n_tri; ti++) {       /* every triangle, index order: the definition */
             hit_rec rec;
-            c->cnt->tri_tests++;
+            ORC_COUNT(c->cnt->tri_tests);
             if (orc_triangle_hit(&c->w->tri[ti], ro, rd, t_min, FLT_MAX, &rec.t, &rec.p, &rec.normal)) {
                 rec.prim = c->w->n_sph + ti; rec.material = c->w->tri[ti].material;
                 if (!have || rec.t < best.t) { best = rec; have = 1; }

@@ -53,9 +53,9 @@ class rt_stats(C.Structure):
 
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_last_rccl_error", "rt_selftest_rccl", "rt_set_flags", "rt_set_tuning", "rt_upload_scene",
-    "rt_scene_info", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts",
-    "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
+    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_last_rccl_error", "rt_selftest_rccl", "rt_set_flags", "rt_set_tuning", "rt_set_cu_mask", "rt_upload_scene",
+    "rt_scene_info", "rt_upload_timing", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts",
+    "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_progressive_begin", "rt_progressive_step", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
     "rt_selftest_math", "rt_selftest_cbrt_grid",
 ]
@@ -94,10 +94,14 @@ def load():
     L.rt_set_flags.restype = C.c_int
     L.rt_set_tuning.argtypes = [vp, C.POINTER(rt_tuning)]
     L.rt_set_tuning.restype = C.c_int
+    L.rt_set_cu_mask.argtypes = [vp, u32p, C.c_uint32]
+    L.rt_set_cu_mask.restype = C.c_int
     L.rt_upload_scene.argtypes = [vp, C.POINTER(rt_spheres), C.POINTER(rt_triangles), C.POINTER(rt_spheres)]
     L.rt_upload_scene.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]
     L.rt_scene_info.restype = C.c_int
+    L.rt_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rt_upload_timing.restype = C.c_int
     L.rt_debug_wave_fill.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rt_debug_wave_fill.restype = C.c_int
     L.rt_last_kernel_name.argtypes = [vp]
@@ -120,6 +124,10 @@ def load():
     L.rt_render_reference_style.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), C.c_uint32, vp,
                                             C.POINTER(rt_stats)]
     L.rt_render_reference_style.restype = C.c_int
+    L.rt_progressive_begin.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), C.c_uint32]
+    L.rt_progressive_begin.restype = C.c_int
+    L.rt_progressive_step.argtypes = [vp, vp, vp, u32p, C.POINTER(rt_stats)]
+    L.rt_progressive_step.restype = C.c_int
     L.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp, C.POINTER(rt_stats)]
     L.rt_render_device.restype = C.c_int
     L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_config), vp, vp, vp]

@@ -232,6 +232,17 @@ class Context:
         t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap)
         self._check(self._L.rt_set_tuning(self._h, C.byref(t)), "rt_set_tuning")
 
+    def set_cu_mask(self, n_cus=None):
+        """rt_set_cu_mask: run this ctx's renders on the first n_cus compute units (mask bits 0..n_cus-1: on MI355X
+        spread evenly over the 8 XCDs); None = the whole GPU."""
+        if n_cus is None:
+            self._check(self._L.rt_set_cu_mask(self._h, None, 0), "rt_set_cu_mask")
+            return
+        words = (n_cus + 31) // 32
+        mask = (C.c_uint32 * words)(*[0xFFFFFFFF if (w + 1) * 32 <= n_cus else (1 << (n_cus - w * 32)) - 1
+                                      for w in range(words)])
+        self._check(self._L.rt_set_cu_mask(self._h, mask, words), "rt_set_cu_mask")
+
     def upload_scene(self, spheres=None, triangles=None, materials=None):
         sv = spheres.view() if spheres is not None else None
         tv = triangles.view() if triangles is not None else None
@@ -245,6 +256,12 @@ class Context:
         vals = [C.c_uint32() for _ in range(4)]
         self._check(self._L.rt_scene_info(self._h, *[C.byref(x) for x in vals]), "rt_scene_info")
         return dict(zip(("n_spheres", "n_triangles", "n_bvh_nodes", "bvh_depth"), [int(x.value) for x in vals]))
+
+    def upload_ms(self):
+        """rt_upload_timing of the last upload: {host_build, device_copy} in ms."""
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self._L.rt_upload_timing(self._h, C.byref(a), C.byref(b)), "rt_upload_timing")
+        return {"host_build": a.value, "device_copy": b.value}
 
     def wave_fill(self):
         """Fill of the BVH kernel's phases in the last RT_FLAG_DEPTH_HISTOGRAM render (profiling aid)."""
@@ -290,6 +307,23 @@ class Context:
                                                rgb8.ctypes.data, C.byref(st))
         self._check(rc, "rt_render_reference_style")
         return rgb8, _stats_tuple(st)
+
+    def render_progressive(self, cam, cfg, n_passes):
+        """rt_progressive_begin / rt_progressive_step as a generator: yields (spp_done, rgb8, accum_mean, stats tuple)
+        after every pass; the arrays are reused between passes."""
+        n = cfg.nx * cfg.ny
+        rgb8 = np.zeros((n, 3), np.uint8)
+        accum = np.zeros((n, 3), np.float32)
+        self._check(self._L.rt_progressive_begin(self._h, C.byref(cam.to_abi()), C.byref(cfg), n_passes),
+                    "rt_progressive_begin")
+        while True:
+            done, st = C.c_uint32(0), rt_stats()
+            rc = self._L.rt_progressive_step(self._h, rgb8.ctypes.data, accum.ctypes.data, C.byref(done), C.byref(st))
+            if rc < 0:
+                raise RtError(rc, "rt_progressive_step", self._L.rt_last_hip_error(self._h))
+            yield int(done.value), rgb8, accum, _stats_tuple(st)
+            if rc == 0:
+                return
 
     def render_device(self, cam, cfg, d_accum_sum, d_raycount=0, stream=0, want_stats=True):
         """rt_render_device: adds into a device accumulation buffer (raw device pointers as ints)."""

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@ struct rt_ctx {
     float4      *d_geom = nullptr, *d_tri = nullptr, *d_aux = nullptr, *d_albedo = nullptr, *d_bvh = nullptr;
     uint32_t     n_sph = 0, n_tri = 0, n_nodes = 0;
     int          bvh_depth = 0;
+    double       upload_build_ms = 0, upload_copy_ms = 0;   // last rt_upload_scene: host BVH build / device allocation + copies
     TraceKernel  last_kernel = RT_K_BRUTE_SPHERES;
     uint64_t     fill_counters[6] = { 0, 0, 0, 0, 0, 0 };
     uint64_t     block_counters[2 * RT_PROF_BLOCKS] = { 0 };
@@ -49,6 +51,12 @@ struct rt_ctx {
     std::vector<void *> rccl_comms;
     std::vector<int>    rccl_devices;
     int          last_rccl = 0;                // ncclResult_t of the last failing RCCL call
+    // rt_progressive_*: the render in progress
+    bool         prog_active = false;
+    rt_camera    prog_cam;
+    rt_config    prog_cfg;
+    uint32_t     prog_passes = 0, prog_next = 0;
+    rt_stats     prog_total;
 };
 
 // ---- rt_render_device_noalloc's scratch -----------------------------------------------------------------
@@ -436,6 +444,30 @@ int rt_set_flags(rt_ctx *ctx, uint32_t flags)
     return RT_OK;
 }
 
+int rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words)
+{
+    if (!ctx || (mask && (n_words == 0 || n_words > 64))) return RT_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    int cus = prop.multiProcessorCount;
+    hipStream_t st = nullptr;
+    if (mask) {
+        cus = 0;
+        for (uint32_t w = 0; w < n_words; ++w)
+            for (uint32_t b = 0; b < 32; ++b)
+                if (w * 32 + b < (uint32_t)prop.multiProcessorCount && ((mask[w] >> b) & 1u)) cus++;
+        if (cus == 0) return RT_E_ARG;
+        HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&st, n_words, mask));
+    } else {
+        HIP_TRY(ctx, hipStreamCreate(&st));
+    }
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    ctx->stream = st;
+    ctx->num_cus = cus;          // the persistent grid is sized for the CUs the stream may use
+    return RT_OK;
+}
+
 int rt_set_tuning(rt_ctx *ctx, const rt_tuning *t)
 {
     if (!ctx) return RT_E_ARG;
@@ -473,6 +505,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         if (!ctx) return RT_E_ARG;
         const bool have_sph = sph && sph->n, have_tri = tri && tri->n;
         if (have_sph == have_tri) return RT_E_ARG;            // exactly one kind of primitive per scene
+        const auto t_begin = std::chrono::steady_clock::now();
         std::vector<float4> geom, tris, aux, alb;
         std::vector<rtbvh::Prim> prims;
         const rt_spheres *mats = have_sph ? sph : materials;
@@ -529,6 +562,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             }
         }
 
+        const auto t_built = std::chrono::steady_clock::now();
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
@@ -545,6 +579,9 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         ctx->n_tri = have_tri ? tri->n : 0;
         ctx->n_nodes = (uint32_t)tree.nodes.size();
         ctx->bvh_depth = tree.depth;
+        const auto t_end = std::chrono::steady_clock::now();
+        ctx->upload_build_ms = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
+        ctx->upload_copy_ms = std::chrono::duration<double, std::milli>(t_end - t_built).count();
         return RT_OK;
     });
 }
@@ -557,6 +594,14 @@ int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles,
     if (n_triangles) *n_triangles = ctx->n_tri;
     if (n_bvh_nodes) *n_bvh_nodes = ctx->n_nodes;
     if (bvh_depth) *bvh_depth = (uint32_t)ctx->bvh_depth;
+    return RT_OK;
+}
+
+int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms)
+{
+    if (!ctx) return RT_E_ARG;
+    if (host_build_ms) *host_build_ms = ctx->upload_build_ms;
+    if (device_copy_ms) *device_copy_ms = ctx->upload_copy_ms;
     return RT_OK;
 }
 
@@ -649,6 +694,62 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *ac
     if (stats) { if ((rc = read_stats(ctx, st, stats)) != RT_OK) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return RT_OK;
+}
+
+int rt_progressive_begin(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_passes)
+{
+    if (!ctx || !cam || n_passes == 0) return RT_E_ARG;
+    int rc = check_config(cfg);
+    if (rc != RT_OK) return rc;
+    if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)cfg->nx * cfg->ny;
+    if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_mean, ctx->mean_cap, npix * 3)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_rgb8, ctx->rgb8_cap, npix * 3)) != RT_OK) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, npix * 3 * sizeof(float), ctx->stream));
+    const uint32_t span = cfg->spp_end - cfg->spp_begin;
+    ctx->prog_cam = *cam; ctx->prog_cfg = *cfg;
+    ctx->prog_passes = n_passes > span ? (span ? span : 1u) : n_passes;
+    ctx->prog_next = 0;
+    std::memset(&ctx->prog_total, 0, sizeof ctx->prog_total);
+    ctx->prog_active = true;
+    return RT_OK;
+}
+
+int rt_progressive_step(rt_ctx *ctx, uint8_t *rgb8, float *accum_mean, uint32_t *spp_done, rt_stats *stats)
+{
+    if (!ctx) return RT_E_ARG;
+    if (!ctx->prog_active) return RT_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const rt_config &cfg = ctx->prog_cfg;
+    const size_t npix = (size_t)cfg.nx * cfg.ny;
+    // pass k renders the k-th contiguous part of [spp_begin, spp_end): sizes differ by at most one, early passes take the extra
+    const uint32_t span = cfg.spp_end - cfg.spp_begin, n = ctx->prog_passes, k = ctx->prog_next;
+    const uint32_t base = span / n, extra = span % n;
+    rt_config sub = cfg;
+    sub.spp_begin = cfg.spp_begin + k * base + (k < extra ? k : extra);
+    sub.spp_end = sub.spp_begin + base + (k < extra ? 1 : 0);
+    hipStream_t st = ctx->stream;
+    int rc = enqueue_trace(ctx, &ctx->prog_cam, &sub, ctx->d_accum, nullptr, st);
+    if (rc != RT_OK) { ctx->prog_active = false; return rc; }
+    // the picture so far: the mean over the samples rendered up to now (the last pass divides by spp_total, as rt_render does)
+    const bool last = k + 1 == n;
+    const uint32_t done = sub.spp_end - cfg.spp_begin;
+    const uint32_t divisor = last ? cfg.spp_total : (done ? done : 1u);
+    HIP_TRY(ctx, rt_launch_tonemap(ctx->d_accum, (uint32_t)npix, divisor, ctx->d_mean, ctx->d_rgb8, st));
+    if (rgb8) HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->d_rgb8, npix * 3, hipMemcpyDeviceToHost, st));
+    if (accum_mean) HIP_TRY(ctx, hipMemcpyAsync(accum_mean, ctx->d_mean, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    rt_stats one;
+    if ((rc = read_stats(ctx, st, &one)) != RT_OK) { ctx->prog_active = false; return rc; }
+    rt_stats &t = ctx->prog_total;
+    t.rays += one.rays; t.primary_rays += one.primary_rays; t.kernel_ms += one.kernel_ms;
+    for (int d = 0; d < 20; ++d) t.rays_by_depth[d] += one.rays_by_depth[d];
+    if (spp_done) *spp_done = done;
+    if (stats) *stats = t;
+    ctx->prog_next = k + 1;
+    if (last) { ctx->prog_active = false; return RT_OK; }
+    return RT_PROGRESS_MORE;
 }
 
 int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, uint32_t n_images,

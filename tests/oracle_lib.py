@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "librt_oracle.so")
+LIB_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(ORACLE_DIR, "librt_oracle.so")   # RT_ORACLE_LIB: bench.py's natively built copy
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 TRAV_LIST, TRAV_BVH_REF, TRAV_BRUTE = 0, 1, 2

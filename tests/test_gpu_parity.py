@@ -706,6 +706,28 @@ def test_reference_style_u8_mean_of_images(gpu_ctx):
     assert img.shape == lin.shape and not np.array_equal(img, lin)
 
 
+def test_progressive_render_converges_to_rt_render(gpu_ctx):
+    """rt_progressive_*: the polling form for the GUI's Trace button (main.zig:307-318,342-345; slot shape of
+    compute.zig:123-207).  Every intermediate picture is the mean over the samples so far (checked against a plain
+    render of exactly those samples), and the last one is rt_render's image with spp_chunk = the pass size, bit for bit."""
+    nx, ny, spp, passes = 96, 54, 12, 4
+    s, cam, _ = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    seen = []
+    for done, rgb8, accum, (rays, prim, _ms, _) in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, spp), passes):
+        seen.append(done)
+        assert prim == nx * ny * done
+        part = gpu_ctx.render(cam, R.make_config(nx, ny, done, spp_chunk=spp // passes))
+        assert np.array_equal(accum.view(np.uint32), part.accum.view(np.uint32)) and np.array_equal(rgb8, part.rgb8)
+        assert rays == part.rays
+    assert seen == [3, 6, 9, 12]
+    with pytest.raises(R.RtError) as e:                        # no render in progress any more
+        gpu_ctx._check(gpu_ctx._L.rt_progressive_step(gpu_ctx._h, None, None, None, None), "rt_progressive_step")
+    assert e.value.code == _lib.RT_E_STATE
+    # more passes than samples: one sample per pass
+    assert [d for d, *_ in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, 3), 10)] == [1, 2, 3]
+
+
 def test_render_and_write_ppm(gpu_ctx, tmp_path):
     """render_and_write (raytracer.zig:580-633) -> the same P3 file the oracle writes for its image."""
     nx, ny, spp = 48, 27, 4
