@@ -530,7 +530,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
             }
         } else {
-            if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= 0x7FFFFFFFu / 3) return RT_E_ARG;
+            if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= (1u << 26)) return RT_E_ARG;   // 26-bit triangle ids in the kernels' candidate entries
             for (uint32_t k = 0; k < tri->n; ++k) {
                 if (tri->material[k] >= mats->n) return RT_E_ARG;
                 const float *a = tri->v0 + 3 * (size_t)k, *b = tri->v1 + 3 * (size_t)k, *c = tri->v2 + 3 * (size_t)k;

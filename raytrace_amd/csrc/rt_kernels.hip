@@ -685,7 +685,17 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     constexpr int BLOCK = NT;
     __shared__ uint32_t s_hist[HIST ? RT_HIST_WORDS + 2 * RT_PROF_BLOCKS : 1];
     __shared__ idx_t s_stack[STACK * BLOCK];          // [entry][thread]: a wave's accesses are conflict-free
-    __shared__ idx_t s_cand[CAND * BLOCK];
+    // Candidates (leaves whose box the ray's cone touches) wait for their exact test.
+    //   spheres:   per-lane queues [entry][thread]; a batch pops one candidate per lane
+    //   triangles: ONE queue per wave, entries {owner lane, triangle}: a batch hands one entry to every lane, whoever
+    //              owns it -- the lane fetches the owner's ray with a wave shuffle, tests, and merges the result into
+    //              the owner's (t, index) word with an LDS atomic min -- so the expensive test runs with full waves
+    //              although a ray meets only three or four leaves on ~30 steps (the per-lane form filled 31 % of it)
+    constexpr bool SHARED_Q = KIND == KIND_BVH_TRIANGLES;
+    constexpr int  WQ_CAP = 64 + 2 * 64;              // at most 63 left over + two candidates per lane and step
+    __shared__ idx_t s_cand[SHARED_Q ? 1 : CAND * BLOCK];
+    __shared__ uint32_t s_wcand[SHARED_Q ? (NT / 64) * WQ_CAP : 1];
+    __shared__ unsigned long long s_wbest[SHARED_Q ? NT : 1];      // per lane: bits(t) << 32 | triangle: min = closest, ties to the lower index
     extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
     const float4 *s_geom = s_scene + (LDSN ? n_nodes * LDS_NODE_STRIDE : 0u);
     __shared__ uint32_t s_wq[2 * (NT / 64)];
@@ -712,6 +722,9 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 
     // traversal state of the lane's current ray
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
+    uint32_t wcount = 0;                              // SHARED_Q: entries in this wave's queue (wave-uniform)
+    uint32_t *const wq = s_wcand + (SHARED_Q ? (tid >> 6) * WQ_CAP : 0);
+    constexpr unsigned long long NO_HIT_KEY = ((unsigned long long)0x7f7fffffu << 32) | 0xFFFFFFFFull;   // (T_MAX, NOHIT)
     float best_t = T_MAX, a = 1.0f;
     // the slab test's ray operands as register pairs, made once per ray (ray_splat).  The empty asm keeps the
     // compiler from re-copying t_min (1 v_mov) on every traversal step.
@@ -731,6 +744,29 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     // (the order of the tests does not matter: the closest hit is the lexicographic minimum of (t, index)).
     // Popping one per lane keeps the batch as full as the number of lanes that hold candidates, instead of
     // looping to the longest queue with ever fewer lanes.
+    // SHARED_Q: one batch = the newest min(64, wcount) entries of the wave's queue, one per lane
+    auto test_batch = [&]() {
+        if (HIST) c_wflush += 1;
+        const uint32_t n = wcount < 64u ? wcount : 64u, base = wcount - n;
+        const bool mine = lane < n;
+        const uint32_t e = mine ? wq[base + lane] : (lane << 26);
+        const uint32_t owner = e >> 26, prim = e & 0x03FFFFFFu;
+        // the owner's ray (every lane takes part in the shuffles: a lane's registers are read by others)
+        Lane R;
+        R.o = mk(__shfl(L.o.x, (int)owner), __shfl(L.o.y, (int)owner), __shfl(L.o.z, (int)owner));
+        R.d = mk(__shfl(L.d.x, (int)owner), __shfl(L.d.y, (int)owner), __shfl(L.d.z, (int)owner));
+        if (mine) {
+            if (HIST) c_lflush += 1;
+            const float4 p0 = tri[3u * prim], p1 = tri[3u * prim + 1u], p2 = tri[3u * prim + 2u];
+            float t = T_MAX; uint32_t hit = NOHIT;
+            triangle_exact(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), prim, R, P.t_min, t, hit);
+            if (hit != NOHIT)       // t > t_min >= 0: the bits of t order like t
+                atomicMin(&s_wbest[(tid & ~63u) + owner], ((unsigned long long)__float_as_uint(t) << 32) | prim);
+        }
+        wcount = base;
+        const unsigned long long k = s_wbest[tid];
+        best_t = __uint_as_float((uint32_t)(k >> 32)); best = (uint32_t)k;
+    };
     auto test_one = [&]() {
         if (HIST) c_wflush += 1;
         if (ncand != 0u) {
@@ -751,7 +787,8 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
         // ---- lanes whose traversal is complete: exact tests, shade, next ray --------------------------
         if (__ballot(node == DONE && (has_ray || alive)) != 0ull) {
             // drain the queues of the finished lanes; lanes still traversing join each batch (their best_t tightens)
-            while (__ballot(node == DONE && ncand != 0u) != 0ull) test_one();
+            if constexpr (SHARED_Q) { while (wcount != 0u) test_batch(); }
+            else { while (__ballot(node == DONE && ncand != 0u) != 0ull) test_one(); }
             if (HIST) c_wshade += 1;
             if (node == DONE) {
                 if (HIST && has_ray) c_lshade += 1;
@@ -776,6 +813,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     a = dot(L.d, L.d);
                     ray_splat(RS, L.o, L.d, a, KIND == KIND_BVH_SPHERES ? RT_CONE_SPHERES : RT_CONE_TRIANGLES);
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
+                    if (SHARED_Q) s_wbest[tid] = NO_HIT_KEY;
                 }
             }
         }
@@ -789,6 +827,8 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
         constexpr bool PERP = decltype(perp_tag)::value;
         for (;;) {
             if (HIST) c_wsteps += 1;
+            bool push0 = false, push1 = false;
+            uint32_t cand0 = 0, cand1 = 0;
             if (node != DONE) {
                 if (HIST) c_lsteps += 1;
                 float tn0, tn1, tf0, tf1;
@@ -798,8 +838,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 const uint2 refs = *(const uint2 *)(nd + NODE_REFS_OFFSET);
                 const uint32_t c0 = refs.x, c1 = refs.y;
                 const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
-                if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
-                if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
+                if constexpr (!SHARED_Q) {
+                    if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
+                    if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
+                }
+                push0 = h0 && l0; push1 = h1 && l1; cand0 = c0 & ~LEAF_BIT; cand1 = c1 & ~LEAF_BIT;
                 const bool v0 = h0 && !l0, v1 = h1 && !l1;
                 if (v0 && v1) {                       // descend into the nearer child, stack the other
                     const bool first0 = tn0 <= tn1;
@@ -820,8 +863,20 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             // run a batch of exact tests when enough lanes hold candidates to fill it (a hit found early also
             // tightens best_t and prunes the rest of that lane's traversal), or when a queue has no room for the
             // two candidates a step can add
-            if ((uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) test_one();
-            while (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
+            if constexpr (SHARED_Q) {
+                // append this step's candidates behind the queue's tail (wave-wide prefix counts: no atomics), then run
+                // full batches
+                const unsigned long long m0 = __ballot(push0), m1 = __ballot(push1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (push0) wq[wcount + (uint32_t)__popcll(m0 & below)] = (lane << 26) | cand0;
+                wcount += (uint32_t)__popcll(m0);
+                if (push1) wq[wcount + (uint32_t)__popcll(m1 & below)] = (lane << 26) | cand1;
+                wcount += (uint32_t)__popcll(m1);
+                while (wcount >= 64u) test_batch();
+            } else {
+                if ((uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) test_one();
+                while (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
+            }
             if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
         }
         };
