@@ -6,9 +6,12 @@
 // primitive tests on the survivors are the exact ones, so the answer is the list's.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <future>
+#include <thread>
 #include <vector>
 
 namespace rtbvh {
@@ -57,10 +60,14 @@ struct Builder {
     std::vector<uint32_t> idx;
     Tree tree;
     int depth_cap = MAX_DEPTH;   // SAH splits that would make the tree deeper than this fall back to the median
+    std::atomic<int> depth_seen{ 0 };
+    std::atomic<int> spare_threads{ 0 };       // subtrees that may still be handed to a thread of their own
     explicit Builder(const std::vector<Prim> &p) : prims(p), idx(p.size()) { for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i; }
 
-    // returns the reference of the subtree over idx[first, first+count) and its box
-    uint32_t build(uint32_t first, uint32_t count, int depth, Box &out_box)
+    // Returns the reference of the subtree over idx[first, first+count) and its box.  A subtree over `count`
+    // primitives has exactly count - 1 inner nodes, so its nodes get the fixed range [me, me + count - 1) of the
+    // (pre-sized) node array in depth-first order: the tree does not depend on which subtrees ran in parallel.
+    uint32_t build(uint32_t first, uint32_t count, int depth, uint32_t me, Box &out_box)
     {
         out_box = Box();
         for (uint32_t i = 0; i < count; ++i) out_box.grow(prims[idx[first + i]].box);
@@ -114,12 +121,20 @@ struct Builder {
             std::nth_element(idx.begin() + first, idx.begin() + first + mid, idx.begin() + first + count,
                              [&](uint32_t a, uint32_t b) { return prims[a].c[ax] < prims[b].c[ax]; });
         }
-        const uint32_t me = (uint32_t)tree.nodes.size();
-        tree.nodes.emplace_back();
-        tree.depth = std::max(tree.depth, depth + 1);
+        for (int seen = depth_seen.load(); seen < depth + 1 && !depth_seen.compare_exchange_weak(seen, depth + 1); ) { }
         Box b0, b1;
-        const uint32_t r0 = build(first, mid, depth + 1, b0);
-        const uint32_t r1 = build(first + mid, count - mid, depth + 1, b1);
+        uint32_t r0, r1;
+        // the two halves touch disjoint ranges of idx and of the node array
+        if (count >= 8192 && spare_threads.fetch_sub(1) > 0) {
+            auto left = std::async(std::launch::async, [&]() { return build(first, mid, depth + 1, me + 1, b0); });
+            r1 = build(first + mid, count - mid, depth + 1, me + mid, b1);
+            r0 = left.get();
+            spare_threads.fetch_add(1);
+        } else {
+            if (count >= 8192) spare_threads.fetch_add(1);
+            r0 = build(first, mid, depth + 1, me + 1, b0);
+            r1 = build(first + mid, count - mid, depth + 1, me + mid, b1);
+        }
         set_child(tree.nodes[me], 0, b0, r0);
         set_child(tree.nodes[me], 1, b1, r1);
         return me;
@@ -131,7 +146,9 @@ struct Builder {
 // Build over `prims` (boxes must already be padded).  nodes[0] is the root.  depth_cap (<= MAX_DEPTH) bounds
 // the number of inner-node levels: a shallower tree needs a smaller per-lane stack in LDS, which buys
 // occupancy for the latency-bound large-scene kernel.  Needs 2^depth_cap >= prims.size().
-inline Tree build(const std::vector<Prim> &prims, int depth_cap = MAX_DEPTH)
+// Large subtrees are built by up to `threads` threads (0 = the host's hardware threads, at most 16); the result
+// is the same tree whatever the thread count.
+inline Tree build(const std::vector<Prim> &prims, int depth_cap = MAX_DEPTH, int threads = 0)
 {
     detail::Builder b(prims);
     b.depth_cap = depth_cap < 1 ? 1 : (depth_cap > MAX_DEPTH ? MAX_DEPTH : depth_cap);
@@ -145,9 +162,12 @@ inline Tree build(const std::vector<Prim> &prims, int depth_cap = MAX_DEPTH)
         return b.tree;
     }
     Box root;
-    b.tree.nodes.reserve(prims.size());
-    b.build(0, (uint32_t)prims.size(), 0, root);
-    return b.tree;
+    b.tree.nodes.resize(prims.size() - 1);
+    const unsigned hw = std::thread::hardware_concurrency();
+    b.spare_threads = threads > 0 ? threads - 1 : (int)std::min(hw ? hw : 1u, 16u) - 1;
+    b.build(0, (uint32_t)prims.size(), 0, 0u, root);
+    b.tree.depth = b.depth_seen.load();
+    return std::move(b.tree);
 }
 
 // Structural check run at every upload (O(n)): every reference in range, every primitive in exactly

@@ -133,6 +133,20 @@ int main()
             ++checked;
         }
     }
+    // large subtrees are built by several threads: the tree must not depend on the thread count
+    {
+        const int n = 60000;
+        std::vector<rtbvh::Prim> prims(n);
+        for (int i = 0; i < n; ++i)
+            prims[i] = rtbvh::sphere_prim((U(rng) - 0.5f) * 40, (U(rng) - 0.5f) * 4, (U(rng) - 0.5f) * 40, 0.01f + U(rng) * 0.2f);
+        const rtbvh::Tree one = rtbvh::build(prims, 24, 1), many = rtbvh::build(prims, 24, 8);
+        if (!rtbvh::validate(one, prims) || !rtbvh::validate(many, prims)) { std::printf("threaded build: validate failed\n"); return 1; }
+        if (one.depth != many.depth || one.nodes.size() != many.nodes.size() ||
+            std::memcmp(one.nodes.data(), many.nodes.data(), one.nodes.size() * sizeof(rtbvh::Node)) != 0) {
+            std::printf("threaded build differs from the single-threaded one\n");
+            return 1;
+        }
+    }
     std::printf("ok: %ld rays agree; max stack %d, max queued candidates %d\n", checked, g_max_sp, g_max_cand);
     return 0;
 }
