@@ -115,7 +115,10 @@ typedef struct {
     uint32_t flush_lanes;         /* BVH kernels: run a batch of exact tests when this many lanes hold a candidate: 1..65 (24) */
     uint32_t keep_traversing;     /* BVH kernels: leave the traversal loop when fewer lanes than this traverse: 1..64 (8; triangles 16) */
     uint32_t force_global_scene;  /* 1: never stage a small scene in LDS */
-    uint32_t bvh_depth_cap;       /* BVH builder: cap on inner-node levels, 8..32 (24); applies to the NEXT rt_upload_scene */
+    uint32_t bvh_depth_cap;       /* BVH builders: cap on inner-node levels, 8..32 (host 24, device 32); applies to the NEXT rt_upload_scene */
+    uint32_t build_on_device;     /* 1: the NEXT rt_upload_scene builds the tree on the GPU (Morton order; about 1.4 ms for 3e5
+                                   * triangles against 50 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
+                                   * (C4 mesh) slower than on the host's SAH tree -- for scenes that change every frame) */
 } rt_tuning;
 int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaults */
 
@@ -136,9 +139,10 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *
 /* What the last upload built (any pointer may be NULL). */
 int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
                   uint32_t *bvh_depth);
-/* Wall time of the last rt_upload_scene: repacking + BVH build + validation on the host, and device allocation +
- * copies (the role of the timings build_BVH prints, raytracer.zig:301-308,690). */
-int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms);
+/* Wall time of the last rt_upload_scene: repacking (+ BVH build + validation, when the host builds) on the host,
+ * device allocation + copies, and the device-side build (0 when the host built) -- the role of the timings build_BVH
+ * prints, raytracer.zig:301-308,690.  Any pointer may be NULL. */
+int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms, double *device_build_ms);
 /* Profiling aid, no reference counterpart: after a render with RT_FLAG_DEPTH_HISTOGRAM on a BVH scene,
  * out = { wave traversal steps, lane traversal steps, wave exact-test iterations, lane exact-test
  * iterations, wave shading passes, lanes shaded } -- lane/(64*wave) is the fill of each phase. */

@@ -43,7 +43,7 @@ class rt_config(C.Structure):
 
 class rt_tuning(C.Structure):
     _fields_ = [("queue_batch", C.c_uint32), ("flush_lanes", C.c_uint32), ("keep_traversing", C.c_uint32),
-                ("force_global_scene", C.c_uint32), ("bvh_depth_cap", C.c_uint32)]
+                ("force_global_scene", C.c_uint32), ("bvh_depth_cap", C.c_uint32), ("build_on_device", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -100,7 +100,7 @@ def load():
     L.rt_upload_scene.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]
     L.rt_scene_info.restype = C.c_int
-    L.rt_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rt_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rt_upload_timing.restype = C.c_int
     L.rt_debug_wave_fill.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rt_debug_wave_fill.restype = C.c_int

@@ -227,9 +227,11 @@ class Context:
     def set_flags(self, flags):
         self._check(self._L.rt_set_flags(self._h, flags), "rt_set_flags")
 
-    def set_tuning(self, queue_batch=0, flush_lanes=0, keep_traversing=0, force_global_scene=0, bvh_depth_cap=0):
-        """rt_set_tuning: kernel tuning knobs of this ctx, 0 = default (bvh_depth_cap applies to the next upload)."""
-        t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap)
+    def set_tuning(self, queue_batch=0, flush_lanes=0, keep_traversing=0, force_global_scene=0, bvh_depth_cap=0,
+                   build_on_device=0):
+        """rt_set_tuning: kernel tuning knobs of this ctx, 0 = default (bvh_depth_cap and build_on_device apply to the
+        next upload)."""
+        t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap, build_on_device)
         self._check(self._L.rt_set_tuning(self._h, C.byref(t)), "rt_set_tuning")
 
     def set_cu_mask(self, n_cus=None):
@@ -258,10 +260,10 @@ class Context:
         return dict(zip(("n_spheres", "n_triangles", "n_bvh_nodes", "bvh_depth"), [int(x.value) for x in vals]))
 
     def upload_ms(self):
-        """rt_upload_timing of the last upload: {host_build, device_copy} in ms."""
-        a, b = C.c_double(0), C.c_double(0)
-        self._check(self._L.rt_upload_timing(self._h, C.byref(a), C.byref(b)), "rt_upload_timing")
-        return {"host_build": a.value, "device_copy": b.value}
+        """rt_upload_timing of the last upload: {host_build, device_copy, device_build} in ms."""
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._check(self._L.rt_upload_timing(self._h, C.byref(a), C.byref(b), C.byref(c)), "rt_upload_timing")
+        return {"host_build": a.value, "device_copy": b.value, "device_build": c.value}
 
     def wave_fill(self):
         """Fill of the BVH kernel's phases in the last RT_FLAG_DEPTH_HISTOGRAM render (profiling aid)."""

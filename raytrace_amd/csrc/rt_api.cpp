@@ -26,13 +26,13 @@ struct rt_ctx {
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
-    rt_tuning    tuning = { 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
+    rt_tuning    tuning = { 0, 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
     int          last_hip = 0;
     // scene (one kind of primitive at a time: spheres or triangles)
     float4      *d_geom = nullptr, *d_tri = nullptr, *d_aux = nullptr, *d_albedo = nullptr, *d_bvh = nullptr;
     uint32_t     n_sph = 0, n_tri = 0, n_nodes = 0;
     int          bvh_depth = 0;
-    double       upload_build_ms = 0, upload_copy_ms = 0;   // last rt_upload_scene: host BVH build / device allocation + copies
+    double       upload_build_ms = 0, upload_copy_ms = 0, upload_device_build_ms = 0;   // last rt_upload_scene: host BVH build / device allocation + copies / device build
     TraceKernel  last_kernel = RT_K_BRUTE_SPHERES;
     uint64_t     fill_counters[6] = { 0, 0, 0, 0, 0, 0 };
     uint64_t     block_counters[2 * RT_PROF_BLOCKS] = { 0 };
@@ -471,13 +471,14 @@ int rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words)
 int rt_set_tuning(rt_ctx *ctx, const rt_tuning *t)
 {
     if (!ctx) return RT_E_ARG;
-    const rt_tuning def = { 0, 0, 0, 0, 0 };
+    const rt_tuning def = { 0, 0, 0, 0, 0, 0 };
     if (!t) t = &def;
     // queue_batch: every wave reserves at most two batches past the end of the queue, and check_config leaves
     // 2^24 item numbers of headroom: 16384 resident waves x 2 x 256 stays inside it
     if (t->queue_batch && (t->queue_batch < 64 || t->queue_batch > 256)) return RT_E_ARG;
     if (t->flush_lanes > 65 || t->keep_traversing > 64) return RT_E_ARG;
     if (t->bvh_depth_cap && (t->bvh_depth_cap < 8 || t->bvh_depth_cap > 32)) return RT_E_ARG;
+    if (t->build_on_device > 1) return RT_E_ARG;
     ctx->tuning = *t;
     return RT_OK;
 }
@@ -509,6 +510,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         std::vector<float4> geom, tris, aux, alb;
         std::vector<rtbvh::Prim> prims;
         const rt_spheres *mats = have_sph ? sph : materials;
+        const uint32_t n_prim = have_sph ? sph->n : tri->n;
+        const bool device_build = ctx->tuning.build_on_device != 0 && n_prim >= 2;   // (the one-primitive tree is a constant)
         if (!spheres_valid(mats, have_sph)) return RT_E_ARG;
         if (mats->n >= 0x7FFFFFFFu) return RT_E_ARG;
         for (uint32_t k = 0; k < mats->n; ++k) {
@@ -527,7 +530,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             for (uint32_t k = 0; k < sph->n; ++k) {
                 const float rad = sph->radius[k];
                 geom.push_back(make_float4(sph->cx[k], sph->cy[k], sph->cz[k], rad * rad));   // raytracer.zig:51
-                prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
+                if (!device_build) prims.push_back(rtbvh::sphere_prim(sph->cx[k], sph->cy[k], sph->cz[k], rad));
             }
         } else {
             if (!tri->v0 || !tri->v1 || !tri->v2 || !tri->material || tri->n >= (1u << 26)) return RT_E_ARG;   // 26-bit triangle ids in the kernels' candidate entries
@@ -538,14 +541,15 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 tris.push_back(make_float4(a[0], a[1], a[2], mat_bits));
                 tris.push_back(make_float4(b[0], b[1], b[2], 0.0f));
                 tris.push_back(make_float4(c[0], c[1], c[2], 0.0f));
-                prims.push_back(rtbvh::triangle_prim(a, b, c));
+                if (!device_build) prims.push_back(rtbvh::triangle_prim(a, b, c));
             }
         }
         const int depth_cap = ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
-        const rtbvh::Tree tree = rtbvh::build(prims, depth_cap);
-        if (!rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
+        const rtbvh::Tree tree = device_build ? rtbvh::Tree() : rtbvh::build(prims, depth_cap);
+        if (!device_build && !rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
         // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)
-        if (tree.nodes.size() * (uint64_t)RT_NODE_BYTES >= 0x80000000ull) return RT_E_ARG;   // byte offsets keep bit 31 free
+        const size_t n_nodes = device_build ? (size_t)n_prim - 1 : tree.nodes.size();
+        if (n_nodes * (uint64_t)RT_NODE_BYTES >= 0x80000000ull) return RT_E_ARG;   // byte offsets keep bit 31 free
         std::vector<float4> nodes(tree.nodes.size() * (RT_NODE_BYTES / 16));
         for (size_t k = 0; k < tree.nodes.size(); ++k) {
             const float *w = tree.nodes[k].w;
@@ -575,13 +579,28 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         if ((rc = upload_vec(ctx, ctx->d_aux, aux)) != RT_OK) return rc;
         if ((rc = upload_vec(ctx, ctx->d_albedo, alb)) != RT_OK) return rc;
         if ((rc = upload_vec(ctx, ctx->d_bvh, nodes)) != RT_OK) return rc;
+        const auto t_copied = std::chrono::steady_clock::now();
+        int depth = tree.depth;
+        if (device_build) {
+            uint32_t bad = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bvh, n_nodes * (size_t)RT_NODE_BYTES));
+            // (the Morton tree is deeper than the SAH tree; under a cap of 24 the forced middle splits cost the C4 trace 25 %)
+            const uint32_t dev_cap = ctx->tuning.bvh_depth_cap ? ctx->tuning.bvh_depth_cap : (uint32_t)rtbvh::MAX_DEPTH;
+            HIP_TRY(ctx, rt_device_build_bvh(have_tri, n_prim, ctx->d_geom, ctx->d_aux, ctx->d_tri, ctx->d_bvh, dev_cap,
+                                             &depth, &bad, ctx->stream));
+            if (bad || depth > rtbvh::MAX_DEPTH) {            // NaN/inf geometry: no scene rather than a tree that lies
+                (void)hipFree(ctx->d_bvh); ctx->d_bvh = nullptr;
+                return RT_E_STATE;
+            }
+        }
         ctx->n_sph = have_sph ? sph->n : 0;
         ctx->n_tri = have_tri ? tri->n : 0;
-        ctx->n_nodes = (uint32_t)tree.nodes.size();
-        ctx->bvh_depth = tree.depth;
+        ctx->n_nodes = (uint32_t)n_nodes;
+        ctx->bvh_depth = depth;
         const auto t_end = std::chrono::steady_clock::now();
         ctx->upload_build_ms = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
-        ctx->upload_copy_ms = std::chrono::duration<double, std::milli>(t_end - t_built).count();
+        ctx->upload_copy_ms = std::chrono::duration<double, std::milli>(t_copied - t_built).count();
+        ctx->upload_device_build_ms = std::chrono::duration<double, std::milli>(t_end - t_copied).count();
         return RT_OK;
     });
 }
@@ -597,11 +616,12 @@ int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles,
     return RT_OK;
 }
 
-int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms)
+int rt_upload_timing(const rt_ctx *ctx, double *host_build_ms, double *device_copy_ms, double *device_build_ms)
 {
     if (!ctx) return RT_E_ARG;
     if (host_build_ms) *host_build_ms = ctx->upload_build_ms;
     if (device_copy_ms) *device_copy_ms = ctx->upload_copy_ms;
+    if (device_build_ms) *device_build_ms = ctx->upload_device_build_ms;
     return RT_OK;
 }
 

@@ -68,6 +68,12 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
                            bool histogram, int num_cus, hipStream_t stream);
 const char *rt_trace_kernel_name(TraceKernel which);
 
+// rt_build.hip: the (n - 1)-node tree of the scene already on the device, built there.  n >= 2; nodes holds
+// (n - 1) * RT_NODE_BYTES bytes; depth_cap <= 32 bounds the inner-node levels (raised to ceil(log2 n) if below);
+// *depth = levels used; *bad != 0: a primitive is not finite.  Synchronises.
+hipError_t rt_device_build_bvh(bool triangles, uint32_t n, const float4 *geom, const float4 *aux, const float4 *tri,
+                               float4 *nodes, uint32_t depth_cap, int *depth, uint32_t *bad, hipStream_t stream);
+
 hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,
                                    size_t plane_stride, hipStream_t stream);
 

@@ -228,10 +228,6 @@ __device__ __forceinline__ void triangle_exact(f3 v0, f3 v1, f3 v2, uint32_t pri
 // boxes and the second the FAR planes (the sign of inv decides which of lo/hi is nearer, and rounding is
 // monotonic, so the selected values are exactly the min and max the generic test would compute).
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 constexpr float RT_CONE_SPHERES = 0x1.08p-10f;      // sqrt(15.5 u) = 0.97 * 2^-10, plus 6 % for the slab rounding, the centre's rounding and second-order terms
 // Moller-Trumbore: u and v are off by ~6 u |o - v0| / (|e| sin(phi) cos(theta)) (phi the triangle's corner angle, theta the
 // angle between ray and normal), i.e. ~6 u |o - v0| / (sin(phi) cos(theta)) in space: 2^-14 covers sin(phi) cos(theta) >= 0.006.

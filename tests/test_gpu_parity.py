@@ -252,6 +252,69 @@ def test_bvh_depth_cap_variants_of_the_triangle_kernel(gpu_ctx, cap):
     _compare(res, oa, o8, orc, cnt)
 
 
+def test_tree_built_on_the_device_gives_the_same_image(gpu_ctx):
+    """rt_tuning.build_on_device: Morton sort + top-down splits made by rt_build.hip (raytracer.zig:279-376).
+    The closest hit does not depend on the tree, so the image and the ray counts equal the host-built tree's bit for
+    bit -- and the oracle's list traversal.  Sphere counts from two up; the mesh is 27 000 triangles; a depth cap at
+    the minimum, ceil(log2 n), forces the middle splits."""
+    rng = np.random.default_rng(5)
+    for n in (2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 100, 485, 700):
+        s = R.Spheres(cx=rng.uniform(-4, 4, n), cy=rng.uniform(-1, 2, n), cz=rng.uniform(-6, -2, n),
+                      radius=rng.uniform(0.05, 0.5, n), kind=rng.integers(0, 3, n), r=rng.uniform(0.2, 1, n),
+                      g=rng.uniform(0.2, 1, n), b=rng.uniform(0.2, 1, n), param=rng.uniform(0.0, 0.3, n) + (rng.integers(0, 2, n) * 1.5))
+        cfg = R.make_config(64, 36, 2)
+        gpu_ctx.upload_scene(s)
+        host = gpu_ctx.render(R.BasicCamera(), cfg, want_raycount=True)
+        try:
+            gpu_ctx.set_tuning(build_on_device=1)
+            gpu_ctx.upload_scene(s)
+        finally:
+            gpu_ctx.set_tuning()
+        info = gpu_ctx.scene_info()
+        assert info["n_bvh_nodes"] == n - 1 and int(np.ceil(np.log2(n))) <= info["bvh_depth"] <= 32, (n, info)
+        assert gpu_ctx.upload_ms()["device_build"] > 0
+        dev = gpu_ctx.render(R.BasicCamera(), cfg, want_raycount=True)
+        assert np.array_equal(dev.raycount, host.raycount), n
+        assert np.array_equal(dev.accum, host.accum), n
+    src = R.Spheres(cx=[0, 0, -1.1, 1.1, 0.3], cy=[0, -100.5, 0, 0, 0.9], cz=[-1, -1, -1, -1, -1.2],
+                    radius=[0.5, 100, 0.5, 0.5, 0.3], kind=[0, 0, 2, 1, 0], r=[.5, .5, .95, .8, .2], g=[.5, .5, .95, .6, .7],
+                    b=[.5, .5, .95, .2, .3], param=[0, 0, 1.5, .15, 0])
+    tris = R.Tessellate_Spheres(src, 60, 45)
+    try:
+        gpu_ctx.set_tuning(build_on_device=1, bvh_depth_cap=15)
+        gpu_ctx.upload_scene(triangles=tris, materials=src)
+        assert gpu_ctx.scene_info()["bvh_depth"] == 15
+        capped = gpu_ctx.render(R.BasicCamera(), R.make_config(96, 54, 4), want_raycount=True)
+        gpu_ctx.set_tuning(build_on_device=1)
+        gpu_ctx.upload_scene(triangles=tris, materials=src)
+    finally:
+        gpu_ctx.set_tuning()
+    info = gpu_ctx.scene_info()
+    assert info["n_bvh_nodes"] == len(tris) - 1 and int(np.ceil(np.log2(len(tris)))) <= info["bvh_depth"] <= 32
+    nx, ny, spp = 96, 54, 4
+    res = gpu_ctx.render(R.BasicCamera(), R.make_config(nx, ny, spp), want_raycount=True)
+    w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(src))
+    oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(nx, ny, spp))
+    _compare(res, oa, o8, orc, cnt)
+    assert np.array_equal(capped.raycount, res.raycount) and np.array_equal(capped.accum, res.accum)
+
+
+def test_device_build_refuses_geometry_that_is_not_finite(gpu_ctx):
+    """The host builder's validation rejects NaN/inf geometry (RT_E_STATE); so does the device builder."""
+    src = R.Spheres(cx=[0, 0], cy=[0, -100.5], cz=[-1, -1], radius=[0.5, 100], kind=[0, 0], r=[.5, .5], g=[.5, .5], b=[.5, .5],
+                    param=[0, 0])
+    tris = R.Tessellate_Spheres(src, 8, 6)
+    tris.v1[5, 1] = np.nan
+    try:
+        gpu_ctx.set_tuning(build_on_device=1)
+        with pytest.raises(R.RtError) as e:
+            gpu_ctx.upload_scene(triangles=tris, materials=src)
+        assert e.value.code == -4                        # RT_E_STATE
+    finally:
+        gpu_ctx.set_tuning()
+    gpu_ctx.upload_scene(R.Two_Sphere_Scene())          # the ctx is still usable
+
+
 def test_sphere_scene_too_big_for_lds_and_radii_without_a_fast_reciprocal(gpu_ctx):
     """(a) Random_Scene(14): ~500 spheres do not fit the LDS-staged variant, the global-memory BVH kernel runs.
     (b) radii whose reciprocal the host refuses to precompute (all-ones significand, far outside 2^+-60) and a

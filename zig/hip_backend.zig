@@ -65,7 +65,7 @@ extern fn rt_destroy(ctx: ?*rt_ctx) void;
 extern fn rt_device_count() c_int;
 extern fn rt_strerror(code: c_int) [*:0]const u8;
 extern fn rt_upload_scene(ctx: ?*rt_ctx, spheres: ?*const rt_spheres, triangles: ?*const rt_triangles, materials: ?*const rt_spheres) c_int;
-extern fn rt_upload_timing(ctx: ?*const rt_ctx, host_build_ms: ?*f64, device_copy_ms: ?*f64) c_int;
+extern fn rt_upload_timing(ctx: ?*const rt_ctx, host_build_ms: ?*f64, device_copy_ms: ?*f64, device_build_ms: ?*f64) c_int;
 extern fn rt_render(ctx: ?*rt_ctx, cam: *const rt_camera, cfg: *const rt_config, accum_mean: ?[*]f32, rgb8: ?[*]u8, raycount: ?[*]u32, stats: ?*rt_stats) c_int;
 extern fn rt_render_multi(ctxs: [*]const ?*rt_ctx, n_ctx: u32, cam: *const rt_camera, cfg: *const rt_config, accum_mean: ?[*]f32, rgb8: ?[*]u8, raycount: ?[*]u32, stats: ?*rt_stats) c_int;
 extern fn rt_render_reference_style(ctx: ?*rt_ctx, cam: *const rt_camera, cfg: *const rt_config, n_images: u32, rgb8: [*]u8, stats: ?*rt_stats) c_int;
