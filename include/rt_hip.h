@@ -119,6 +119,8 @@ typedef struct {
     uint32_t build_on_device;     /* 1: the NEXT rt_upload_scene builds the tree on the GPU (Morton order; about 1.4 ms for 3e5
                                    * triangles against 50 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
                                    * (C4 mesh) slower than on the host's SAH tree -- for scenes that change every frame) */
+    uint32_t unpacked_nodes;      /* 1: the NEXT rt_upload_scene keeps 80-byte tree nodes for a large triangle scene (default: 72-byte
+                                   * nodes with the child refs folded into the planes' low mantissa bits: one load fewer per step) */
 } rt_tuning;
 int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaults */
 

@@ -26,7 +26,8 @@ struct rt_ctx {
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
-    rt_tuning    tuning = { 0, 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
+    rt_tuning    tuning = { 0, 0, 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
+    bool         bvh_packed = false;              // d_bvh holds RT_PACKED_NODE_BYTES nodes
     int          last_hip = 0;
     // scene (one kind of primitive at a time: spheres or triangles)
     float4      *d_geom = nullptr, *d_tri = nullptr, *d_aux = nullptr, *d_albedo = nullptr, *d_bvh = nullptr;
@@ -300,7 +301,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
     DeviceScene s;
     s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;
-    s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth;
+    s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth; s.packed = ctx->bvh_packed;
     ctx->last_kernel = pick_kernel(ctx);
     float *d_partial = fixed ? fixed->partial : ctx->d_partial;
     if (p.n_chunks > 1) {        // scratch planes for the per-chunk partial sums (every cell is written)
@@ -471,16 +472,34 @@ int rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words)
 int rt_set_tuning(rt_ctx *ctx, const rt_tuning *t)
 {
     if (!ctx) return RT_E_ARG;
-    const rt_tuning def = { 0, 0, 0, 0, 0, 0 };
+    const rt_tuning def = { 0, 0, 0, 0, 0, 0, 0 };
     if (!t) t = &def;
     // queue_batch: every wave reserves at most two batches past the end of the queue, and check_config leaves
     // 2^24 item numbers of headroom: 16384 resident waves x 2 x 256 stays inside it
     if (t->queue_batch && (t->queue_batch < 64 || t->queue_batch > 256)) return RT_E_ARG;
     if (t->flush_lanes > 65 || t->keep_traversing > 64) return RT_E_ARG;
     if (t->bvh_depth_cap && (t->bvh_depth_cap < 8 || t->bvh_depth_cap > 32)) return RT_E_ARG;
-    if (t->build_on_device > 1) return RT_E_ARG;
+    if (t->build_on_device > 1 || t->unpacked_nodes > 1) return RT_E_ARG;
     ctx->tuning = *t;
     return RT_OK;
+}
+
+// Largest float <= v (down) or smallest float >= v (up) whose low mantissa byte is `payload`: the packed node format
+// (rt_kernels.h) carries the child refs in those bytes, and a plane may only move outward.
+static float with_low_byte(float v, uint32_t payload, bool down)
+{
+    if (!down) return -with_low_byte(-v, payload, true);
+    uint32_t b; std::memcpy(&b, &v, 4);
+    for (int step = 0; step < 4; ++step) {
+        const uint32_t cb = (b & ~0xFFu) | payload;
+        float f; std::memcpy(&f, &cb, 4);
+        if (f <= v) return f;
+        // one block of 256 floats towards -infinity
+        if (b & 0x80000000u) b += 0x100u;
+        else if ((b & ~0xFFu) == 0u) b = 0x80000000u;
+        else b -= 0x100u;
+    }
+    return -INFINITY;
 }
 
 static int upload_vec(rt_ctx *ctx, float4 *&dst, const std::vector<float4> &src)
@@ -550,8 +569,28 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)
         const size_t n_nodes = device_build ? (size_t)n_prim - 1 : tree.nodes.size();
         if (n_nodes * (uint64_t)RT_NODE_BYTES >= 0x80000000ull) return RT_E_ARG;   // byte offsets keep bit 31 free
-        std::vector<float4> nodes(tree.nodes.size() * (RT_NODE_BYTES / 16));
-        for (size_t k = 0; k < tree.nodes.size(); ++k) {
+        // large triangle scenes (not the ones the kernels stage in LDS): packed 72-byte nodes, refs inside the planes
+        const bool packed = have_tri && !device_build && !ctx->tuning.unpacked_nodes && n_nodes < (1u << 23) && n_prim < (1u << 23) &&
+                            (n_nodes * (size_t)RT_NODE_BYTES > 40 * 1024 || tree.depth > 16);
+        std::vector<float> pnodes(packed ? n_nodes * (size_t)(RT_PACKED_NODE_BYTES / 4) : 0);
+        for (size_t k = 0; packed && k < tree.nodes.size(); ++k) {
+            const float *w = tree.nodes[k].w;
+            float *d = pnodes.data() + k * (RT_PACKED_NODE_BYTES / 4);
+            uint32_t ref[2];
+            for (int c = 0; c < 2; ++c) {
+                uint32_t r; std::memcpy(&r, &w[12 + c], 4);
+                ref[c] = (r & rtbvh::LEAF_BIT) ? (RT_PACKED_LEAF_BIT | (r & ~rtbvh::LEAF_BIT)) : r;
+            }
+            for (int ax = 0; ax < 3; ++ax) {
+                const uint32_t b0 = (ref[0] >> (8 * ax)) & 0xFFu, b1 = (ref[1] >> (8 * ax)) & 0xFFu;
+                const float lo0 = with_low_byte(w[ax], b0, true), hi0 = with_low_byte(w[3 + ax], b0, false);
+                const float lo1 = with_low_byte(w[6 + ax], b1, true), hi1 = with_low_byte(w[9 + ax], b1, false);
+                float *a = d + 6 * ax;
+                a[0] = hi0; a[1] = hi1; a[2] = lo0; a[3] = lo1; a[4] = hi0; a[5] = hi1;
+            }
+        }
+        std::vector<float4> nodes(packed ? 0 : tree.nodes.size() * (RT_NODE_BYTES / 16));
+        for (size_t k = 0; !packed && k < tree.nodes.size(); ++k) {
             const float *w = tree.nodes[k].w;
             float *d = reinterpret_cast<float *>(nodes.data() + k * (RT_NODE_BYTES / 16));
             for (int ax = 0; ax < 3; ++ax) {
@@ -579,6 +618,11 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         if ((rc = upload_vec(ctx, ctx->d_aux, aux)) != RT_OK) return rc;
         if ((rc = upload_vec(ctx, ctx->d_albedo, alb)) != RT_OK) return rc;
         if ((rc = upload_vec(ctx, ctx->d_bvh, nodes)) != RT_OK) return rc;
+        if (packed) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bvh, pnodes.size() * sizeof(float)));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_bvh, pnodes.data(), pnodes.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        ctx->bvh_packed = packed;
         const auto t_copied = std::chrono::steady_clock::now();
         int depth = tree.depth;
         if (device_build) {

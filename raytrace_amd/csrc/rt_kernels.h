@@ -40,6 +40,11 @@ struct TraceParams {
 // {near0, near1, far0, far1} without a min/max --, then the two child refs at byte 72: bit 31 set = primitive index,
 // else the BYTE offset of the child node.  Made from the host tree (rt_bvh.hpp) at upload, rt_api.cpp.
 constexpr int RT_NODE_BYTES = 80;
+// Packed node of large triangle scenes, 72 bytes: the three axis records only; child c's 24-bit ref (bit 23 = leaf:
+// primitive index below it, else the child's node INDEX) is spread over the low mantissa bytes of its planes -- byte k
+// of the ref in BOTH lo_c and hi_c of axis k (x, y, z), planes rounded outward to the next float carrying that byte.
+constexpr int RT_PACKED_NODE_BYTES = 72;
+constexpr uint32_t RT_PACKED_LEAF_BIT = 0x800000u;
 
 struct DeviceScene {
     const float4 *geom = nullptr;
@@ -50,6 +55,7 @@ struct DeviceScene {
     uint32_t      n_prim = 0;
     uint32_t      n_nodes = 0;
     int           bvh_depth = 0;
+    bool          packed = false;        // bvh holds RT_PACKED_NODE_BYTES nodes (triangles only)
 };
 
 enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANGLES = 2 };

@@ -306,11 +306,9 @@ struct __attribute__((aligned(8))) PlanePairs { v2f near_, far_; };   // 16 byte
 // at the edge of the range) is dropped by them, which only loosens the test.
 #define RT_PKFMA(dst, planes, op) "v_pk_fma_f32 " dst ", " planes ", " op ", " op " op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
 template <bool PERP>
-__device__ __forceinline__ void box2_hit_fma(const char *node, const RaySplat &R, float t_lo, float t_hi,
+__device__ __forceinline__ void box2_hit_fma(PlanePairs px, PlanePairs py, PlanePairs pz, const RaySplat &R, float t_lo, float t_hi,
                                              float &n0, float &n1, float &f0, float &f1)
 {
-    PlanePairs px = *(const PlanePairs *)(node + R.ox), py = *(const PlanePairs *)(node + R.oy),
-               pz = *(const PlanePairs *)(node + R.oz);
     // two statements: the halves of the packed results can only be named through the compiler (sub-registers, no copies)
     v2f xe = (v2f){ 0, 0 }, ye = (v2f){ 0, 0 }, ze = (v2f){ 0, 0 };
     if (PERP)
@@ -669,7 +667,12 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
 // through L1/L2.
 constexpr int LDS_NODE_STRIDE = RT_NODE_BYTES / 16;    // float4 per node
 
-template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT>
+// PACKED (large triangle scenes): 72-byte nodes without the refs record -- the vector L1 serves ~2 divergent lane
+// requests per clock whatever their width (tools/ubench/gather_rate.hip) and this kernel is bound by that rate, so
+// the step's fourth load is folded into the other three: child c's 24-bit ref (bit 23 = leaf, else node INDEX) rides
+// in the low mantissa byte of its x, y and z planes (lo and hi carry the same byte, so the byte arrives whichever
+// way the ray runs; the host rounds the planes outward to the next float with that byte, rt_api.cpp).
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false>
 __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     const TraceParams P,
     const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
@@ -828,17 +831,30 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if (node != DONE) {
                 if (HIST) c_lsteps += 1;
                 float tn0, tn1, tf0, tf1;
-                const char *nd = (LDSN ? (const char *)s_scene : (const char *)bvh) + node;   // node = byte offset
-                box2_hit_fma<PERP>(nd, RS, t_min_v, best_t, tn0, tn1, tf0, tf1);
-                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                const uint2 refs = *(const uint2 *)(nd + NODE_REFS_OFFSET);
-                const uint32_t c0 = refs.x, c1 = refs.y;
-                const bool l0 = (c0 & LEAF_BIT) != 0u, l1 = (c1 & LEAF_BIT) != 0u;
-                if constexpr (!SHARED_Q) {
-                    if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF_BIT); ncand += 1; }
-                    if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF_BIT); ncand += 1; }
+                // node = byte offset (PACKED: node index)
+                const char *nd = (LDSN ? (const char *)s_scene : (const char *)bvh) + (PACKED ? (size_t)node * RT_PACKED_NODE_BYTES : (size_t)node);
+                const PlanePairs px = *(const PlanePairs *)(nd + RS.ox), py = *(const PlanePairs *)(nd + RS.oy),
+                                 pz = *(const PlanePairs *)(nd + RS.oz);
+                uint32_t c0, c1;
+                constexpr uint32_t LEAF = PACKED ? RT_PACKED_LEAF_BIT : LEAF_BIT;
+                if constexpr (PACKED) {
+                    // {x.b0, y.b0, z.b0} of the near planes of child 0 (.x) and child 1 (.y): two v_perm_b32 each
+                    const uint32_t xy0 = __builtin_amdgcn_perm(__float_as_uint(py.near_.x), __float_as_uint(px.near_.x), 0x0c0c0400u);
+                    const uint32_t xy1 = __builtin_amdgcn_perm(__float_as_uint(py.near_.y), __float_as_uint(px.near_.y), 0x0c0c0400u);
+                    c0 = __builtin_amdgcn_perm(__float_as_uint(pz.near_.x), xy0, 0x0c040100u);
+                    c1 = __builtin_amdgcn_perm(__float_as_uint(pz.near_.y), xy1, 0x0c040100u);
+                } else {
+                    const uint2 refs = *(const uint2 *)(nd + NODE_REFS_OFFSET);
+                    c0 = refs.x; c1 = refs.y;
                 }
-                push0 = h0 && l0; push1 = h1 && l1; cand0 = c0 & ~LEAF_BIT; cand1 = c1 & ~LEAF_BIT;
+                box2_hit_fma<PERP>(px, py, pz, RS, t_min_v, best_t, tn0, tn1, tf0, tf1);
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                const bool l0 = (c0 & LEAF) != 0u, l1 = (c1 & LEAF) != 0u;
+                if constexpr (!SHARED_Q) {
+                    if (h0 && l0) { s_cand[ncand * BLOCK + tid] = (idx_t)(c0 & ~LEAF); ncand += 1; }
+                    if (h1 && l1) { s_cand[ncand * BLOCK + tid] = (idx_t)(c1 & ~LEAF); ncand += 1; }
+                }
+                push0 = h0 && l0; push1 = h1 && l1; cand0 = c0 & ~LEAF; cand1 = c1 & ~LEAF;
                 const bool v0 = h0 && !l0, v1 = h1 && !l1;
                 if (v0 && v1) {                       // descend into the nearer child, stack the other
                     const bool first0 = tn0 <= tn1;
@@ -988,11 +1004,11 @@ static bool fits_lds(const DeviceScene &s, bool spheres)
     return s.bvh_depth <= 16 && s.n_nodes < 65536u && s.n_prim < 32768u && lds_scene_bytes(s, spheres) <= 40 * 1024;
 }
 
-template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT>
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false>
 hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, float *partial, uint32_t *raycount,
                       uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
 {
-    auto kern = rt_trace_bvh_kernel<KIND, STACK, CAND, HIST, LDSN, NT>;
+    auto kern = rt_trace_bvh_kernel<KIND, STACK, CAND, HIST, LDSN, NT, PACKED>;
     const size_t dyn = LDSN ? lds_scene_bytes(s, KIND == KIND_BVH_SPHERES) : 0;
     const long long grid = grid_for((const void *)kern, p, num_cus, NT, dyn);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), dyn, stream,
@@ -1042,6 +1058,12 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
     return histogram ? launch_bvh<KIND, 32, 8, true, false, 256>(RT_ARGS)                                  \
                      : launch_bvh<KIND, 32, 8, false, false, 256>(RT_ARGS);
     if (spheres) { RT_BVH(KIND_BVH_SPHERES) }
+    if (s.packed) {
+        if (s.bvh_depth <= 24) return histogram ? launch_bvh<KIND_BVH_TRIANGLES, 24, 7, true, false, 256, true>(RT_ARGS)
+                                                : launch_bvh<KIND_BVH_TRIANGLES, 24, 7, false, false, 256, true>(RT_ARGS);
+        return histogram ? launch_bvh<KIND_BVH_TRIANGLES, 32, 8, true, false, 256, true>(RT_ARGS)
+                         : launch_bvh<KIND_BVH_TRIANGLES, 32, 8, false, false, 256, true>(RT_ARGS);
+    }
     RT_BVH(KIND_BVH_TRIANGLES)
 #undef RT_BVH
 #undef RT_ARGS

@@ -299,6 +299,36 @@ def test_tree_built_on_the_device_gives_the_same_image(gpu_ctx):
     assert np.array_equal(capped.raycount, res.raycount) and np.array_equal(capped.accum, res.accum)
 
 
+def test_packed_tree_nodes_give_the_same_image(gpu_ctx):
+    """Large triangle scenes get 72-byte nodes whose child refs ride in the low mantissa byte of the planes (one load
+    fewer per traversal step; rt_kernels.h RT_PACKED_NODE_BYTES); rt_tuning.unpacked_nodes keeps the 80-byte nodes.
+    The planes only move outward, so the image is the same bit for bit -- and equal to the oracle's.  The mesh sits
+    far from the origin on one axis and straddles zero on another so that the rounding of negative, tiny and large
+    plane values is exercised."""
+    src = R.Spheres(cx=[300.0, 300.0, 298.9, 301.1, 300.3], cy=[0, -100.5, 0, 0, 0.9], cz=[-1, -1, -1, -1, -1.2],
+                    radius=[0.5, 100, 0.5, 0.5, 0.3], kind=[0, 0, 2, 1, 0], r=[.5, .5, .95, .8, .2], g=[.5, .5, .95, .6, .7],
+                    b=[.5, .5, .95, .2, .3], param=[0, 0, 1.5, .15, 0])
+    tris = R.Tessellate_Spheres(src, 60, 45)
+    frm, at = (303.0, 1.5, 3.0), (300.0, 0.0, -1.0)
+    cam = R.MovableCamera().SetPosition(frm, at, (0.0, 1.0, 0.0), 40.0, 96 / 54)
+    ocam = O.camera_set_position(frm, at, (0.0, 1.0, 0.0), 40.0, 96 / 54)
+    cfg = R.make_config(96, 54, 4)
+    images = []
+    for unpacked in (1, 0):
+        try:
+            gpu_ctx.set_tuning(unpacked_nodes=unpacked)
+            gpu_ctx.upload_scene(triangles=tris, materials=src)
+        finally:
+            gpu_ctx.set_tuning()
+        images.append(gpu_ctx.render(cam, cfg, want_raycount=True))
+    assert images[0].rays > 96 * 54 * 4 * 1.5                 # the camera does see the mesh
+    assert np.array_equal(images[0].raycount, images[1].raycount)
+    assert np.array_equal(images[0].accum, images[1].accum)
+    w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(src))
+    oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(96, 54, 4))
+    _compare(images[1], oa, o8, orc, cnt)
+
+
 def test_device_build_refuses_geometry_that_is_not_finite(gpu_ctx):
     """The host builder's validation rejects NaN/inf geometry (RT_E_STATE); so does the device builder."""
     src = R.Spheres(cx=[0, 0], cy=[0, -100.5], cz=[-1, -1], radius=[0.5, 100], kind=[0, 0], r=[.5, .5], g=[.5, .5], b=[.5, .5],

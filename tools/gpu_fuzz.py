@@ -70,7 +70,8 @@ for case in range(n_cases):
     flags = 0
     if mesh:
         tris = R.Tessellate_Spheres(s, int(rng.integers(3, 24)), int(rng.integers(2, 16)))
-        ctx.set_tuning(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])))
+        ctx.set_tuning(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])), unpacked_nodes=int(rng.integers(0, 2)),
+                       build_on_device=int(rng.random() < 0.25))
         ctx.upload_scene(triangles=tris, materials=s)
         w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(s))
         what = "mesh %6d tris" % len(tris)
