@@ -832,9 +832,12 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 if (HIST) c_lsteps += 1;
                 float tn0, tn1, tf0, tf1;
                 // node = byte offset (PACKED: node index)
-                const char *nd = (LDSN ? (const char *)s_scene : (const char *)bvh) + (PACKED ? (size_t)node * RT_PACKED_NODE_BYTES : (size_t)node);
-                const PlanePairs px = *(const PlanePairs *)(nd + RS.ox), py = *(const PlanePairs *)(nd + RS.oy),
-                                 pz = *(const PlanePairs *)(nd + RS.oz);
+                // 32-bit byte offsets from a wave-uniform base: the loads take the base from SGPRs (no 64-bit address math)
+                const char *const nbase = LDSN ? (const char *)s_scene : (const char *)bvh;
+                const uint32_t noff = PACKED ? __umul24(node, (uint32_t)RT_PACKED_NODE_BYTES) : node;   // node index < 2^23
+                const char *nd = nbase + noff;
+                const PlanePairs px = *(const PlanePairs *)(nbase + (noff + RS.ox)), py = *(const PlanePairs *)(nbase + (noff + RS.oy)),
+                                 pz = *(const PlanePairs *)(nbase + (noff + RS.oz));
                 uint32_t c0, c1;
                 constexpr uint32_t LEAF = PACKED ? RT_PACKED_LEAF_BIT : LEAF_BIT;
                 if constexpr (PACKED) {
