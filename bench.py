@@ -232,6 +232,17 @@ def main():
                             "valu_wave_insts_per_64_rays": d.get("valu_wave_insts_per_64_rays"),
                             "lane_utilisation": d.get("valu_lane_utilisation"),
                             "source": "profiles/latest_%s_pmc.json (SQ_THREAD_CYCLES_VALU, SQ_INSTS_VALU)" % args.workload}
+        # what binds the global-memory tree walk (C4): the vector L1 serves ~1.93 divergent lane requests per clock and
+        # CU whatever their width (tools/ubench/gather_rate.hip); requests per clock of the committed counter pass
+        l1 = None
+        if world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                d = json.load(f).get("derived", {})
+            if "l1_requests_per_clk_per_cu" in d:
+                l1 = {"requests_per_clk_per_cu": d["l1_requests_per_clk_per_cu"], "measured_gather_peak": 1.93,
+                      "frac": d["l1_requests_per_clk_per_cu"] / 1.93, "requests_per_ray": d.get("l1_requests_per_ray"),
+                      "l1_hit_rate": d.get("l1_hit_rate"),
+                      "source": "profiles/latest_%s_pmc.json (TCP_TOTAL_CACHE_ACCESSES, TCP_TCC_READ_REQ)" % args.workload}
         out = {
             "metric": "Mrays/sec (all bounces) book scene 1080p 100spp; %FP32 VALU roofline @1/8 GPU",   # BASELINE.json, verbatim
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,7 +255,7 @@ def main():
                        "parallelism": "spp-range x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "executed": executed,
+                         "executed": executed, "l1_gather": l1,
                          "scope": "rank 0's GPU" if world > 1 else "the GPU",
                          "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
