@@ -261,7 +261,13 @@ int orc_sphere_hit(const orc_sphere *s, orc_v3 ro, orc_v3 rd, float t_min, float
 
 /* Build-defined ray-triangle test (Moller-Trumbore, two-sided).  The reference has none
  * (SURVEY 8(a) T1).  Flat normal = normalize(cross(v1-v0, v2-v0)): outward for the
- * par_shapes winding, inward when the owning sphere's radius is negative. */
+ * par_shapes winding, inward when the owning sphere's radius is negative.
+ * Grazing guard (part of the definition): det = |d| |e1| |e2| sin(phi) cos(theta) (phi the corner angle at v0, theta the
+ * angle between ray and normal), and the barycentrics' rounding error, ~7 ulps of |o - v0|, is divided by that product:
+ * without a floor on it the test accepts rays that pass arbitrarily far from the triangle when the origin is far away,
+ * and no culling structure could then be conservative.  A ray with sin(phi) cos(theta) < 2^-7 (0.45 degrees off the
+ * triangle's plane for a right-angled corner) misses by definition; what is accepted then lies within 7 * 2^-17 |o - v0|
+ * of the triangle, inside the cone the cull tests use (2^-13). */
 int orc_triangle_hit(const orc_triangle *tr, orc_v3 ro, orc_v3 rd, float t_min, float t_max,
                      float *t, orc_v3 *p, orc_v3 *normal)
 {
@@ -270,6 +276,7 @@ int orc_triangle_hit(const orc_triangle *tr, orc_v3 ro, orc_v3 rd, float t_min, 
     const orc_v3 pvec = orc_cross(rd, e2);
     const float det = orc_dot(e1, pvec);
     if (!(det != 0.0f)) return 0;               /* parallel (or NaN) */
+    if (!(det * det >= ((orc_dot(rd, rd) * orc_dot(e1, e1)) * orc_dot(e2, e2)) * 0x1.0p-14f)) return 0;   /* grazing */
     const float inv_det = 1.0f / det;
     const orc_v3 tvec = vsub(ro, tr->v0);
     const float u = orc_dot(tvec, pvec) * inv_det;
@@ -479,15 +486,16 @@ static uint32_t tri_build(orc_world *w, uint32_t first, uint32_t count)
 }
 /* Cull test of the checker's triangle BVH.  It must never reject a box that holds a triangle orc_triangle_hit would
  * accept, for any ray origin: Moller-Trumbore's barycentrics are off by a few ulps of |o - v0| ACROSS the ray, and
- * the slab arithmetic rounds relative to the distance.  So the ray is widened into a cone of half-angle 2^-14
- * (f64 arithmetic, plain formulas; speed does not matter here): at parameter t the box is grown by g t, g = 2^-14 |d|.
+ * the slab arithmetic rounds relative to the distance.  So the ray is widened into a cone of half-angle 2^-13
+ * (f64 arithmetic, plain formulas; speed does not matter here): at parameter t the box is grown by g t, g = 2^-13 |d|
+ * (orc_triangle_hit's grazing guard bounds what the test can accept to 7 * 2^-17 |o - v0| around the triangle).
  * Axis k: o_k + t (d_k + g) >= lo_k and o_k + t (d_k - g) <= hi_k.  The nodes' static padding (tri_build) covers
  * origins next to a triangle. */
 static int tri_box_hit(const tri_node *n, orc_v3 ro, orc_v3 rd, float t_min, float t_max)
 {
     const double o[3] = { ro.x, ro.y, ro.z }, d[3] = { rd.x, rd.y, rd.z };
     const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    const double g = len * (1.0 / 16384.0);
+    const double g = len * (1.0 / 8192.0);
     double lo = t_min, hi = t_max;
     if (!(len > 0.0) || !(len < 1e300)) return 1;          /* degenerate ray: no culling (the exact tests reject it) */
     for (int k = 0; k < 3; k++) {

@@ -192,6 +192,14 @@ def test_triangle_hit_cases():
     assert hit((-0.1, 0.25, 0), (0, 0, -1)) == 0
     assert hit((0.25, 0.25, 0), (1, 0, 0)) == 0           # parallel
     assert hit((0.25, 0.25, 0), (0, 0, -1), tmax=1.5) == 0
+    # grazing guard (part of the test's definition): sin(corner angle) * cos(angle to the normal) >= 2^-7.  The
+    # corner at v0 is a right angle, so a ray that meets the plane at slope s = |d_z| / |d| hits iff s >= 2^-7.
+    for slope, expect in ((0.02, 1), (0.0085, 1), (0.0075, 0), (0.001, 0)):
+        dz = -slope / np.sqrt(1.0 - slope * slope)            # direction (1, 0, dz): slope against the plane z = -2
+        ro = (0.25 - 1.0, 0.25, -2.0 - dz)                    # reaches (0.25, 0.25, -2) at t = 1
+        assert hit(ro, (1.0, 0.0, dz)) == expect, slope
+        if expect:
+            assert abs(t.value - 1.0) < 1e-3
 
 
 def test_sky():

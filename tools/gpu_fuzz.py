@@ -2,7 +2,7 @@
 image sizes, sample ranges, chunk sizes, depth caps and seeds; every case compares per-pixel ray counts (exact)
 and the linear mean (1e-3) with the oracle.  Prints one line per case and a summary; stops at the first failure.
 
-    python tools/gpu_fuzz.py [n_cases] [seed]
+    python tools/gpu_fuzz.py [n_cases] [seed] [first_case]      (cases before first_case are generated but not run)
 """
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -29,6 +29,7 @@ def telephoto(frm, at, half_extent, nx, ny):
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = R.Context(0)
 t0 = time.time()
 worst = 0.0
@@ -68,16 +69,24 @@ for case in range(n_cases):
         ocam = O.camera_set_position(frm, at, (0.0, 1.0, 0.0), vfov, asp)
     mesh = n <= 40 and rng.random() < 0.35
     flags = 0
+    tuning = {}
     if mesh:
-        tris = R.Tessellate_Spheres(s, int(rng.integers(3, 24)), int(rng.integers(2, 16)))
-        ctx.set_tuning(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])), unpacked_nodes=int(rng.integers(0, 2)),
-                       build_on_device=int(rng.random() < 0.25))
+        slices, stacks = int(rng.integers(3, 24)), int(rng.integers(2, 16))
+        tuning = dict(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])), unpacked_nodes=int(rng.integers(0, 2)),
+                      build_on_device=int(rng.random() < 0.25))
+    else:
+        flags = int(rng.choice([0, 0, R.RT_FLAG_FORCE_BRUTE_FORCE if n <= 150 else 0, R.RT_FLAG_FORCE_BVH]))
+        tuning = dict(force_global_scene=int(rng.random() < 0.2))
+    if case < first_case:
+        continue
+    if mesh:
+        tris = R.Tessellate_Spheres(s, slices, stacks)
+        ctx.set_tuning(**tuning)
         ctx.upload_scene(triangles=tris, materials=s)
         w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(s))
         what = "mesh %6d tris" % len(tris)
     else:
-        flags = int(rng.choice([0, 0, R.RT_FLAG_FORCE_BRUTE_FORCE if n <= 150 else 0, R.RT_FLAG_FORCE_BVH]))
-        ctx.set_tuning(force_global_scene=int(rng.random() < 0.2))
+        ctx.set_tuning(**tuning)
         ctx.set_flags(flags)
         ctx.upload_scene(s)
         w = O.World(spheres=spheres_to_oracle(s))
@@ -99,6 +108,20 @@ for case in range(n_cases):
     if not ok:
         bad = np.flatnonzero(res.raycount != orc)
         print("  mismatching pixels:", bad[:10], res.raycount[bad[:10]], orc[bad[:10]])
+        d = np.abs(np.nan_to_num(res.accum) - np.nan_to_num(oa)).max(axis=1)
+        wp = np.argsort(d)[::-1][:5]
+        print("  tuning", tuning, "flags", flags, "scene_info", ctx.scene_info(), "far", far)
+        print("  worst pixels", wp, "gpu", res.accum[wp].tolist(), "oracle", oa[wp].tolist(), "raycounts", res.raycount[wp], orc[wp])
+        if mesh:                                   # the checker's plain loop over all triangles; which tree variant deviates?
+            ba, b8, brc, bcnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, spp_chunk=ochunk, traversal=O.TRAV_BRUTE, **kw))
+            print("   oracle plain loop: vs oracle BVH err", float(np.abs(np.nan_to_num(ba) - np.nan_to_num(oa)).max()),
+                  "; vs GPU err", float(np.abs(np.nan_to_num(ba) - np.nan_to_num(res.accum)).max()),
+                  "raycounts equal GPU", np.array_equal(brc, res.raycount), "pixel", ba[wp[0]].tolist())
+            for alt in (dict(unpacked_nodes=1), dict(), dict(build_on_device=1), dict(unpacked_nodes=1, bvh_depth_cap=32)):
+                ctx.set_tuning(**alt); ctx.upload_scene(triangles=tris, materials=s)
+                r2 = ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=chunk, **kw), want_raycount=True)
+                print("   variant", alt, "err", float(np.abs(np.nan_to_num(r2.accum) - np.nan_to_num(oa)).max()),
+                      "raycounts equal", np.array_equal(r2.raycount, orc), "pixel", r2.accum[wp[0]].tolist())
         np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), cx=cx, cy=cy, cz=cz, rad=rad, kind=kind, param=param)
         sys.exit(1)
 print("fuzz: %d cases ok, worst |err| %.3g, %.0f s" % (n_cases, worst, time.time() - t0))
