@@ -75,13 +75,15 @@ struct Builder {
 
         Box cb;
         for (uint32_t i = 0; i < count; ++i) cb.grow(prims[idx[first + i]].c);
-        // binned SAH over the three axes
-        constexpr int NB = 16;
+        // binned SAH over the three axes; 32 bins for large scenes (C4: the trace runs 3 % faster on that tree than on the
+        // 16-bin one, 11 % faster than on the 8-bin one), 16 for the small ones, where it makes no difference
+        constexpr int NBMAX = 32;
+        const int NB = prims.size() >= 4096 ? 32 : 16;
         float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
         for (int ax = 0; ax < 3; ++ax) {
             const float ext = cb.hi[ax] - cb.lo[ax];
             if (!(ext > 0)) continue;
-            Box bb[NB]; uint32_t bc[NB] = { 0 };
+            Box bb[NBMAX]; uint32_t bc[NBMAX] = { 0 };
             const float scale = NB / ext;
             for (uint32_t i = 0; i < count; ++i) {
                 const Prim &p = prims[idx[first + i]];
@@ -89,7 +91,7 @@ struct Builder {
                 b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
                 bb[b].grow(p.box); bc[b]++;
             }
-            float right_area[NB]; uint32_t right_cnt[NB];
+            float right_area[NBMAX]; uint32_t right_cnt[NBMAX];
             Box acc; uint32_t cnt = 0;
             for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
             acc = Box(); cnt = 0;
