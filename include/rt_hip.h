@@ -154,6 +154,10 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6]);
  * work-item dequeue, Philox, camera ray, random_in_unit_sphere, cbrt fallback, lambertian, metal, dielectric,
  * hit-normal IEEE fallback.  Returns the number of values written (24) or RT_E_CAP. */
 int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out);
+/* Test aid, no reference counterpart, host arithmetic only (no GPU needed): the plane rounding of the packed tree nodes
+ * (rt_tuning.unpacked_nodes) -- the largest float <= v (down != 0) or the smallest float >= v (down == 0) whose low
+ * mantissa byte equals payload (0..255). */
+float rt_debug_round_plane(float v, uint32_t payload, int down);
 /* Name of the trace kernel the last render launched (for profiles). */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 

@@ -676,6 +676,8 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6])
     return RT_OK;
 }
 
+float rt_debug_round_plane(float v, uint32_t payload, int down) { return with_low_byte(v, payload & 0xFFu, down != 0); }
+
 int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out)
 {
     if (!ctx || !out) return RT_E_ARG;

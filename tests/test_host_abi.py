@@ -48,6 +48,30 @@ def test_no_gpu_fails_loudly():
     assert e.value.code == _lib.RT_E_HIP
 
 
+def test_packed_node_plane_rounding_only_moves_outward():
+    """The packed tree nodes (rt_kernels.h RT_PACKED_NODE_BYTES) carry a byte of a child reference in the low mantissa
+    byte of every plane; the host rounds a lower plane down and an upper plane up to the nearest float with that byte.
+    Checked here on the host: the byte is there, the plane never moves inward, and it moves by less than 512 ulps --
+    across signs, zero, denormals and large magnitudes."""
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([
+        (rng.standard_normal(4000) * 10.0 ** rng.integers(-6, 7, 4000)).astype(np.float32),
+        np.array([0.0, -0.0, 1e-45, -1e-45, 3e-39, -3e-39, 1.17549435e-38, -1.17549435e-38, 1.0, -1.0, 255.0, -1000.0, 1e30, -1e30],
+                 dtype=np.float32)])
+    for v in vals:
+        for payload in (0, 1, 127, 128, 255, int(rng.integers(0, 256))):
+            for down in (1, 0):
+                r = np.float32(L.rt_debug_round_plane(float(v), payload, down))
+                assert int(r.view(np.uint32)) & 0xFF == payload, (v, payload, down, r)
+                assert (r <= v) if down else (r >= v), (v, payload, down, r)
+                # at most two blocks of 256 floats away (ordered-integer distance)
+                def key(x):
+                    b = int(np.float32(x).view(np.uint32))
+                    return (0x80000000 - (b & 0x7FFFFFFF)) if b & 0x80000000 else (0x80000000 + b)
+                assert abs(key(r) - key(v)) < 512, (v, payload, down, r)
+
+
 def test_cameras_match_oracle_bitwise():
     assert np.array_equal(R.BasicCamera().as_array(), O.camera_basic().as_array())
     for nx, ny in ((1200, 675), (1920, 1080), (400, 225), (64, 36)):
