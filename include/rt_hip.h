@@ -119,9 +119,15 @@ typedef struct {
     uint32_t build_on_device;     /* 1: the NEXT rt_upload_scene builds the tree on the GPU (Morton order; about 1.4 ms for 3e5
                                    * triangles against 50 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
                                    * (C4 mesh) slower than on the host's SAH tree -- for scenes that change every frame) */
-    uint32_t unpacked_nodes;      /* 1: the NEXT rt_upload_scene keeps 80-byte tree nodes for a large triangle scene (default: 72-byte
-                                   * nodes with the child refs folded into the planes' low mantissa bits: one load fewer per step) */
+    uint32_t node_format;         /* tree nodes of the NEXT rt_upload_scene of a large triangle scene (host build): 0 = default (RT_NODES_WIDE),
+                                   * RT_NODES_BINARY80 = two children, 80 bytes with a refs record; RT_NODES_BINARY72 = two children, 72
+                                   * bytes, the child refs folded into the planes' low mantissa bytes (one load fewer per step);
+                                   * RT_NODES_WIDE = up to four children (two binary levels collapsed), 144 bytes, refs folded likewise
+                                   * (half as many steps per ray).  Same image whatever the format */
 } rt_tuning;
+#define RT_NODES_BINARY80 1u
+#define RT_NODES_BINARY72 2u
+#define RT_NODES_WIDE 3u
 int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaults */
 
 /* Restrict the ctx's own stream to a subset of the GPU's compute units (hipExtStreamCreateWithCUMask; bit i of
@@ -155,7 +161,7 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6]);
  * hit-normal IEEE fallback.  Returns the number of values written (24) or RT_E_CAP. */
 int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out);
 /* Test aid, no reference counterpart, host arithmetic only (no GPU needed): the plane rounding of the packed tree nodes
- * (rt_tuning.unpacked_nodes) -- the largest float <= v (down != 0) or the smallest float >= v (down == 0) whose low
+ * (rt_tuning.node_format) -- the largest float <= v (down != 0) or the smallest float >= v (down == 0) whose low
  * mantissa byte equals payload (0..255). */
 float rt_debug_round_plane(float v, uint32_t payload, int down);
 /* Name of the trace kernel the last render launched (for profiles). */

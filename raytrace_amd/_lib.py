@@ -43,7 +43,8 @@ class rt_config(C.Structure):
 
 class rt_tuning(C.Structure):
     _fields_ = [("queue_batch", C.c_uint32), ("flush_lanes", C.c_uint32), ("keep_traversing", C.c_uint32),
-                ("force_global_scene", C.c_uint32), ("bvh_depth_cap", C.c_uint32), ("build_on_device", C.c_uint32), ("unpacked_nodes", C.c_uint32)]
+                ("force_global_scene", C.c_uint32), ("bvh_depth_cap", C.c_uint32), ("build_on_device", C.c_uint32), ("node_format", C.c_uint32)]
+RT_NODES_BINARY80, RT_NODES_BINARY72, RT_NODES_WIDE = 1, 2, 3
 
 
 class rt_stats(C.Structure):

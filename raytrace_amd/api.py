@@ -228,10 +228,10 @@ class Context:
         self._check(self._L.rt_set_flags(self._h, flags), "rt_set_flags")
 
     def set_tuning(self, queue_batch=0, flush_lanes=0, keep_traversing=0, force_global_scene=0, bvh_depth_cap=0,
-                   build_on_device=0, unpacked_nodes=0):
+                   build_on_device=0, node_format=0):
         """rt_set_tuning: kernel tuning knobs of this ctx, 0 = default (bvh_depth_cap and build_on_device apply to the
         next upload)."""
-        t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap, build_on_device, unpacked_nodes)
+        t = rt_tuning(queue_batch, flush_lanes, keep_traversing, force_global_scene, bvh_depth_cap, build_on_device, node_format)
         self._check(self._L.rt_set_tuning(self._h, C.byref(t)), "rt_set_tuning")
 
     def set_cu_mask(self, n_cus=None):

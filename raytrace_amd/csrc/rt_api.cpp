@@ -27,6 +27,7 @@ struct rt_ctx {
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
     rt_tuning    tuning = { 0, 0, 0, 0, 0, 0, 0 };   // 0 = the library's default for that knob
+    bool         bvh_wide = false;                // d_bvh holds RT_WIDE_NODE_BYTES nodes
     bool         bvh_packed = false;              // d_bvh holds RT_PACKED_NODE_BYTES nodes
     int          last_hip = 0;
     // scene (one kind of primitive at a time: spheres or triangles)
@@ -301,7 +302,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
     DeviceScene s;
     s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;
-    s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth; s.packed = ctx->bvh_packed;
+    s.n_prim = p.n_prim; s.n_nodes = ctx->n_nodes; s.bvh_depth = ctx->bvh_depth; s.packed = ctx->bvh_packed; s.wide = ctx->bvh_wide;
     ctx->last_kernel = pick_kernel(ctx);
     float *d_partial = fixed ? fixed->partial : ctx->d_partial;
     if (p.n_chunks > 1) {        // scratch planes for the per-chunk partial sums (every cell is written)
@@ -479,7 +480,7 @@ int rt_set_tuning(rt_ctx *ctx, const rt_tuning *t)
     if (t->queue_batch && (t->queue_batch < 64 || t->queue_batch > 256)) return RT_E_ARG;
     if (t->flush_lanes > 65 || t->keep_traversing > 64) return RT_E_ARG;
     if (t->bvh_depth_cap && (t->bvh_depth_cap < 8 || t->bvh_depth_cap > 32)) return RT_E_ARG;
-    if (t->build_on_device > 1 || t->unpacked_nodes > 1) return RT_E_ARG;
+    if (t->build_on_device > 1 || t->node_format > RT_NODES_WIDE) return RT_E_ARG;
     ctx->tuning = *t;
     return RT_OK;
 }
@@ -563,14 +564,69 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 if (!device_build) prims.push_back(rtbvh::triangle_prim(a, b, c));
             }
         }
-        const int depth_cap = ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
+        // wide nodes: two binary levels per node and up to 3 stack entries per wide level, 32-entry stacks -> binary cap 22
+        const uint32_t fmt = ctx->tuning.node_format ? ctx->tuning.node_format : RT_NODES_WIDE;
+        const bool want_wide = have_tri && !device_build && fmt == RT_NODES_WIDE && n_prim >= 1024u && n_prim <= (1u << 22) &&
+                               (!ctx->tuning.bvh_depth_cap || ctx->tuning.node_format == RT_NODES_WIDE);   // (an explicit cap asks for a binary tree of that depth)
+        const int depth_cap = want_wide ? 22 : ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
         const rtbvh::Tree tree = device_build ? rtbvh::Tree() : rtbvh::build(prims, depth_cap);
         if (!device_build && !rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
         // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)
         const size_t n_nodes = device_build ? (size_t)n_prim - 1 : tree.nodes.size();
         if (n_nodes * (uint64_t)RT_NODE_BYTES >= 0x80000000ull) return RT_E_ARG;   // byte offsets keep bit 31 free
         // large triangle scenes (not the ones the kernels stage in LDS): packed 72-byte nodes, refs inside the planes
-        const bool packed = have_tri && !device_build && !ctx->tuning.unpacked_nodes && n_nodes < (1u << 23) && n_prim < (1u << 23) &&
+        // 4-wide nodes: node k of the binary tree and its (inner) children become one node over the grandchildren
+        std::vector<float> wnodes;
+        int wide_depth = 0;
+        if (want_wide) {
+            struct Item { uint32_t bin; uint32_t wide; int level; };
+            std::vector<Item> todo{ { 0u, 0u, 1 } };
+            uint32_t n_wide = 1;
+            const float inf = INFINITY;
+            auto slot = [&](uint32_t wi) { if (wnodes.size() < (size_t)(wi + 1) * (RT_WIDE_NODE_BYTES / 4)) wnodes.resize((size_t)(wi + 1) * (RT_WIDE_NODE_BYTES / 4)); return wnodes.data() + (size_t)wi * (RT_WIDE_NODE_BYTES / 4); };
+            while (!todo.empty()) {
+                const Item it = todo.back(); todo.pop_back();
+                wide_depth = std::max(wide_depth, it.level);
+                // gather up to four (box, ref) pairs: a leaf child stays, an inner child is replaced by its two children
+                float lo[4][3], hi[4][3]; uint32_t ref[4]; bool inner[4]; int nc = 0;
+                const float *w = tree.nodes[it.bin].w;
+                for (int c = 0; c < 2; ++c) {
+                    uint32_t r; std::memcpy(&r, &w[12 + c], 4);
+                    if (r & rtbvh::LEAF_BIT) {
+                        for (int k = 0; k < 3; ++k) { lo[nc][k] = w[6 * c + k]; hi[nc][k] = w[6 * c + 3 + k]; }
+                        ref[nc] = r; inner[nc] = false; nc++;
+                    } else {
+                        const float *g = tree.nodes[r].w;
+                        for (int cc = 0; cc < 2; ++cc) {
+                            uint32_t rr; std::memcpy(&rr, &g[12 + cc], 4);
+                            for (int k = 0; k < 3; ++k) { lo[nc][k] = g[6 * cc + k]; hi[nc][k] = g[6 * cc + 3 + k]; }
+                            ref[nc] = rr; inner[nc] = !(rr & rtbvh::LEAF_BIT); nc++;
+                        }
+                    }
+                }
+                uint32_t packed_ref[4] = { 0, 0, 0, 0 };
+                for (int c = 0; c < nc; ++c) {
+                    if (inner[c]) { packed_ref[c] = n_wide; todo.push_back({ ref[c], n_wide, it.level + 1 }); n_wide++; }
+                    else packed_ref[c] = RT_PACKED_LEAF_BIT | (ref[c] & ~rtbvh::LEAF_BIT);
+                }
+                float *d = slot(it.wide);
+                for (int ax = 0; ax < 3; ++ax) {
+                    float *a = d + 12 * ax;                                  // {hi0..hi3, lo0..lo3, hi0..hi3}
+                    for (int c = 0; c < 4; ++c) {
+                        float l = inf, h = -inf;
+                        if (c < nc) {
+                            const uint32_t b = (packed_ref[c] >> (8 * ax)) & 0xFFu;
+                            l = with_low_byte(lo[c][ax], b, true); h = with_low_byte(hi[c][ax], b, false);
+                        }
+                        a[c] = h; a[4 + c] = l; a[8 + c] = h;
+                    }
+                }
+            }
+            if (n_wide >= (1u << 23) || wide_depth > 11) return RT_E_STATE;
+            wnodes.resize((size_t)n_wide * (RT_WIDE_NODE_BYTES / 4));
+        }
+        const bool wide = want_wide;
+        const bool packed = !wide && have_tri && !device_build && fmt != RT_NODES_BINARY80 && n_nodes < (1u << 23) && n_prim < (1u << 23) &&
                             (n_nodes * (size_t)RT_NODE_BYTES > 40 * 1024 || tree.depth > 16);
         std::vector<float> pnodes(packed ? n_nodes * (size_t)(RT_PACKED_NODE_BYTES / 4) : 0);
         for (size_t k = 0; packed && k < tree.nodes.size(); ++k) {
@@ -589,8 +645,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 a[0] = hi0; a[1] = hi1; a[2] = lo0; a[3] = lo1; a[4] = hi0; a[5] = hi1;
             }
         }
-        std::vector<float4> nodes(packed ? 0 : tree.nodes.size() * (RT_NODE_BYTES / 16));
-        for (size_t k = 0; !packed && k < tree.nodes.size(); ++k) {
+        std::vector<float4> nodes(packed || wide ? 0 : tree.nodes.size() * (RT_NODE_BYTES / 16));
+        for (size_t k = 0; !packed && !wide && k < tree.nodes.size(); ++k) {
             const float *w = tree.nodes[k].w;
             float *d = reinterpret_cast<float *>(nodes.data() + k * (RT_NODE_BYTES / 16));
             for (int ax = 0; ax < 3; ++ax) {
@@ -622,7 +678,12 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bvh, pnodes.size() * sizeof(float)));
             HIP_TRY(ctx, hipMemcpy(ctx->d_bvh, pnodes.data(), pnodes.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (wide) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bvh, wnodes.size() * sizeof(float)));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_bvh, wnodes.data(), wnodes.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         ctx->bvh_packed = packed;
+        ctx->bvh_wide = wide;
         const auto t_copied = std::chrono::steady_clock::now();
         int depth = tree.depth;
         if (device_build) {
@@ -639,8 +700,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         }
         ctx->n_sph = have_sph ? sph->n : 0;
         ctx->n_tri = have_tri ? tri->n : 0;
-        ctx->n_nodes = (uint32_t)n_nodes;
-        ctx->bvh_depth = depth;
+        ctx->n_nodes = wide ? (uint32_t)(wnodes.size() / (RT_WIDE_NODE_BYTES / 4)) : (uint32_t)n_nodes;
+        ctx->bvh_depth = wide ? wide_depth : depth;
         const auto t_end = std::chrono::steady_clock::now();
         ctx->upload_build_ms = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
         ctx->upload_copy_ms = std::chrono::duration<double, std::milli>(t_copied - t_built).count();

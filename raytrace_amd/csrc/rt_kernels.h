@@ -45,6 +45,13 @@ constexpr int RT_NODE_BYTES = 80;
 // of the ref in BOTH lo_c and hi_c of axis k (x, y, z), planes rounded outward to the next float carrying that byte.
 constexpr int RT_PACKED_NODE_BYTES = 72;
 constexpr uint32_t RT_PACKED_LEAF_BIT = 0x800000u;
+// Wide node of large triangle scenes (rt_tuning.wide_nodes), 144 bytes: two levels of the binary tree collapsed into one
+// node of up to four children -- half as many dependent node fetches per ray.  Per axis (48 bytes)
+// {hi0..hi3, lo0..lo3, hi0..hi3}: a lane reads 32 bytes at +16 (ray runs up the axis) or +0 (down) and gets
+// {near0..near3, far0..far3}.  Refs as in the packed node (24 bits in the low mantissa bytes of the child's planes;
+// inner = index of a wide node).  A missing child has lo = +inf, hi = -inf (never hit) and a zero ref.
+constexpr int RT_WIDE_NODE_BYTES = 144;
+constexpr int RT_WIDE_STACK = 32;        // 3 pushes per level: trees of at most 11 wide levels (binary depth cap 22)
 
 struct DeviceScene {
     const float4 *geom = nullptr;
@@ -56,6 +63,7 @@ struct DeviceScene {
     uint32_t      n_nodes = 0;
     int           bvh_depth = 0;
     bool          packed = false;        // bvh holds RT_PACKED_NODE_BYTES nodes (triangles only)
+    bool          wide = false;          // bvh holds RT_WIDE_NODE_BYTES nodes (triangles only); bvh_depth = wide levels
 };
 
 enum TraceKernel { RT_K_BRUTE_SPHERES = 0, RT_K_BVH_SPHERES = 1, RT_K_BVH_TRIANGLES = 2 };

@@ -677,7 +677,10 @@ constexpr int LDS_NODE_STRIDE = RT_NODE_BYTES / 16;    // float4 per node
 // the step's fourth load is folded into the other three: child c's 24-bit ref (bit 23 = leaf, else node INDEX) rides
 // in the low mantissa byte of its x, y and z planes (lo and hi carry the same byte, so the byte arrives whichever
 // way the ray runs; the host rounds the planes outward to the next float with that byte, rt_api.cpp).
-template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false>
+// WIDE (rt_tuning.wide_nodes): 144-byte nodes of up to four children (rt_kernels.h RT_WIDE_NODE_BYTES), refs packed as
+// above (PACKED is set with it): a step tests four boxes with two of the two-box slab tests, queues the hit leaves,
+// descends into the nearest hit inner child and stacks the others.
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false, bool WIDE = false>
 __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     const TraceParams P,
     const float4 *__restrict__ geom, const float4 *__restrict__ tri, const float4 *__restrict__ aux,
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     //              the owner's (t, index) word with an LDS atomic min -- so the expensive test runs with full waves
     //              although a ray meets only three or four leaves on ~30 steps (the per-lane form filled 31 % of it)
     constexpr bool SHARED_Q = KIND == KIND_BVH_TRIANGLES;
-    constexpr int  WQ_CAP = 64 + 2 * 64;              // at most 63 left over + two candidates per lane and step
+    constexpr int  WQ_CAP = 64 + (WIDE ? 4 : 2) * 64; // at most 63 left over + two (WIDE: four) candidates per lane and step
     __shared__ idx_t s_cand[SHARED_Q ? 1 : CAND * BLOCK];
     __shared__ uint32_t s_wcand[SHARED_Q ? (NT / 64) * WQ_CAP : 1];
     __shared__ unsigned long long s_wbest[SHARED_Q ? NT : 1];      // per lane: bits(t) << 32 | triangle: min = closest, ties to the lower index
@@ -816,6 +819,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 if (has_ray) {                        // start the new ray at the root
                     a = dot(L.d, L.d);
                     ray_splat(RS, L.o, L.d, a, KIND == KIND_BVH_SPHERES ? RT_CONE_SPHERES : RT_CONE_TRIANGLES);
+                    if (WIDE) {                       // wide axis record {hi x4, lo x4, hi x4}: near quad at +16 (up) or +0 (down), far quad behind it
+                        RS.ox = ((__float_as_uint(L.d.x) >> 31) ^ 1u) << 4;
+                        RS.oy = 48u + (((__float_as_uint(L.d.y) >> 31) ^ 1u) << 4);
+                        RS.oz = 96u + (((__float_as_uint(L.d.z) >> 31) ^ 1u) << 4);
+                    }
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                     if (SHARED_Q) s_wbest[tid] = NO_HIT_KEY;
                 }
@@ -831,6 +839,75 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
         constexpr bool PERP = decltype(perp_tag)::value;
         for (;;) {
             if (HIST) c_wsteps += 1;
+            if constexpr (WIDE) {
+                bool push[4] = { false, false, false, false };
+                uint32_t cand[4] = { 0, 0, 0, 0 };
+                if (node != DONE) {
+                    if (HIST) c_lsteps += 1;
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const char *const nbase = (const char *)bvh;
+                    const uint32_t noff = __umul24(node, (uint32_t)RT_WIDE_NODE_BYTES);
+                    const v4f xn = *(const v4f *)(nbase + (noff + RS.ox)), xf = *(const v4f *)(nbase + (noff + RS.ox + 16u));
+                    const v4f yn = *(const v4f *)(nbase + (noff + RS.oy)), yf = *(const v4f *)(nbase + (noff + RS.oy + 16u));
+                    const v4f zn = *(const v4f *)(nbase + (noff + RS.oz)), zf = *(const v4f *)(nbase + (noff + RS.oz + 16u));
+                    uint32_t c[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t xy = __builtin_amdgcn_perm(__float_as_uint(yn[k]), __float_as_uint(xn[k]), 0x0c0c0400u);
+                        c[k] = __builtin_amdgcn_perm(__float_as_uint(zn[k]), xy, 0x0c040100u);
+                    }
+                    float tn[4], tf[4];
+                    {
+                        const PlanePairs px = { (v2f){ xn.x, xn.y }, (v2f){ xf.x, xf.y } }, py = { (v2f){ yn.x, yn.y }, (v2f){ yf.x, yf.y } },
+                                         pz = { (v2f){ zn.x, zn.y }, (v2f){ zf.x, zf.y } };
+                        box2_hit_fma<PERP>(px, py, pz, RS, t_min_v, best_t, tn[0], tn[1], tf[0], tf[1]);
+                    }
+                    {
+                        const PlanePairs px = { (v2f){ xn.z, xn.w }, (v2f){ xf.z, xf.w } }, py = { (v2f){ yn.z, yn.w }, (v2f){ yf.z, yf.w } },
+                                         pz = { (v2f){ zn.z, zn.w }, (v2f){ zf.z, zf.w } };
+                        box2_hit_fma<PERP>(px, py, pz, RS, t_min_v, best_t, tn[2], tn[3], tf[2], tf[3]);
+                    }
+                    // hit inner children sorted by entry distance (five compare-exchanges): descend into the nearest, stack the
+                    // others farthest first (missing children never hit; a leaf or a miss sorts behind everything)
+                    float key[4];
+                    uint32_t ref[4];
+                    uint32_t nv = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool h = tn[k] <= tf[k], l = (c[k] & RT_PACKED_LEAF_BIT) != 0u;
+                        push[k] = h && l; cand[k] = c[k] & ~RT_PACKED_LEAF_BIT;
+                        const bool v = h && !l;
+                        key[k] = v ? tn[k] : __builtin_inff(); ref[k] = c[k];
+                        nv += v ? 1u : 0u;
+                    }
+#define RT_CE(i, j) { const bool sw = key[j] < key[i]; const float ki = key[i], kj = key[j]; const uint32_t ri = ref[i], rj = ref[j]; \
+                      key[i] = sw ? kj : ki; key[j] = sw ? ki : kj; ref[i] = sw ? rj : ri; ref[j] = sw ? ri : rj; }
+                    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+                    if (nv > 3u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[3]; sp += 1; }
+                    if (nv > 2u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[2]; sp += 1; }
+                    if (nv > 1u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[1]; sp += 1; }
+                    const uint32_t near_c = nv > 0u ? ref[0] : DONE;
+                    if (near_c != DONE) {
+                        node = near_c;
+                    } else if (sp > 0) {
+                        sp -= 1;
+                        node = s_stack[sp * BLOCK + tid];
+                    } else {
+                        node = DONE;
+                    }
+                }
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long m = __ballot(push[k]);
+                    if (push[k]) wq[wcount + (uint32_t)__popcll(m & below)] = (lane << 26) | cand[k];
+                    wcount += (uint32_t)__popcll(m);
+                }
+                while (wcount >= 64u) test_batch();
+                if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
+                continue;
+            }
             bool push0 = false, push1 = false;
             uint32_t cand0 = 0, cand1 = 0;
             if (node != DONE) {
@@ -1012,11 +1089,11 @@ static bool fits_lds(const DeviceScene &s, bool spheres)
     return s.bvh_depth <= 16 && s.n_nodes < 65536u && s.n_prim < 32768u && lds_scene_bytes(s, spheres) <= 40 * 1024;
 }
 
-template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false>
+template <int KIND, int STACK, int CAND, bool HIST, bool LDSN, int NT, bool PACKED = false, bool WIDE = false>
 hipError_t launch_bvh(const TraceParams &p, const DeviceScene &s, float *accum_sum, float *partial, uint32_t *raycount,
                       uint32_t *queue, unsigned long long *stats, int num_cus, hipStream_t stream)
 {
-    auto kern = rt_trace_bvh_kernel<KIND, STACK, CAND, HIST, LDSN, NT, PACKED>;
+    auto kern = rt_trace_bvh_kernel<KIND, STACK, CAND, HIST, LDSN, NT, PACKED, WIDE>;
     const size_t dyn = LDSN ? lds_scene_bytes(s, KIND == KIND_BVH_SPHERES) : 0;
     const long long grid = grid_for((const void *)kern, p, num_cus, NT, dyn);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), dyn, stream,
@@ -1066,6 +1143,11 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
     return histogram ? launch_bvh<KIND, 32, 8, true, false, 256>(RT_ARGS)                                  \
                      : launch_bvh<KIND, 32, 8, false, false, 256>(RT_ARGS);
     if (spheres) { RT_BVH(KIND_BVH_SPHERES) }
+    if (s.wide) {
+        if (spheres || s.bvh_depth > 11) return hipErrorInvalidValue;      // 3 stack entries per wide level
+        return histogram ? launch_bvh<KIND_BVH_TRIANGLES, RT_WIDE_STACK, 8, true, false, 256, true, true>(RT_ARGS)
+                         : launch_bvh<KIND_BVH_TRIANGLES, RT_WIDE_STACK, 8, false, false, 256, true, true>(RT_ARGS);
+    }
     if (s.packed) {
         if (s.bvh_depth <= 24) return histogram ? launch_bvh<KIND_BVH_TRIANGLES, 24, 7, true, false, 256, true>(RT_ARGS)
                                                 : launch_bvh<KIND_BVH_TRIANGLES, 24, 7, false, false, 256, true>(RT_ARGS);

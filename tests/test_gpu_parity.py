@@ -301,7 +301,7 @@ def test_tree_built_on_the_device_gives_the_same_image(gpu_ctx):
 
 def test_packed_tree_nodes_give_the_same_image(gpu_ctx):
     """Large triangle scenes get 72-byte nodes whose child refs ride in the low mantissa byte of the planes (one load
-    fewer per traversal step; rt_kernels.h RT_PACKED_NODE_BYTES); rt_tuning.unpacked_nodes keeps the 80-byte nodes.
+    fewer per traversal step; rt_kernels.h RT_PACKED_NODE_BYTES); and, by default, four-wide 144-byte nodes over two binary levels; rt_tuning.node_format selects.
     The planes only move outward, so the image is the same bit for bit -- and equal to the oracle's.  The mesh sits
     far from the origin on one axis and straddles zero on another so that the rounding of negative, tiny and large
     plane values is exercised."""
@@ -314,19 +314,20 @@ def test_packed_tree_nodes_give_the_same_image(gpu_ctx):
     ocam = O.camera_set_position(frm, at, (0.0, 1.0, 0.0), 40.0, 96 / 54)
     cfg = R.make_config(96, 54, 4)
     images = []
-    for unpacked in (1, 0):
+    for fmt in (_lib.RT_NODES_BINARY80, _lib.RT_NODES_BINARY72, _lib.RT_NODES_WIDE, 0):
         try:
-            gpu_ctx.set_tuning(unpacked_nodes=unpacked)
+            gpu_ctx.set_tuning(node_format=fmt)
             gpu_ctx.upload_scene(triangles=tris, materials=src)
         finally:
             gpu_ctx.set_tuning()
         images.append(gpu_ctx.render(cam, cfg, want_raycount=True))
     assert images[0].rays > 96 * 54 * 4 * 1.5                 # the camera does see the mesh
-    assert np.array_equal(images[0].raycount, images[1].raycount)
-    assert np.array_equal(images[0].accum, images[1].accum)
+    for other in images[1:]:
+        assert np.array_equal(images[0].raycount, other.raycount)
+        assert np.array_equal(images[0].accum, other.accum)
     w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(src))
     oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(96, 54, 4))
-    _compare(images[1], oa, o8, orc, cnt)
+    _compare(images[3], oa, o8, orc, cnt)
 
 
 def test_device_build_refuses_geometry_that_is_not_finite(gpu_ctx):

@@ -72,7 +72,7 @@ for case in range(n_cases):
     tuning = {}
     if mesh:
         slices, stacks = int(rng.integers(3, 24)), int(rng.integers(2, 16))
-        tuning = dict(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])), unpacked_nodes=int(rng.integers(0, 2)),
+        tuning = dict(bvh_depth_cap=int(rng.choice([8, 12, 16, 24, 32])), node_format=int(rng.integers(0, 4)),
                       build_on_device=int(rng.random() < 0.25))
     else:
         flags = int(rng.choice([0, 0, R.RT_FLAG_FORCE_BRUTE_FORCE if n <= 150 else 0, R.RT_FLAG_FORCE_BVH]))
@@ -117,7 +117,7 @@ for case in range(n_cases):
             print("   oracle plain loop: vs oracle BVH err", float(np.abs(np.nan_to_num(ba) - np.nan_to_num(oa)).max()),
                   "; vs GPU err", float(np.abs(np.nan_to_num(ba) - np.nan_to_num(res.accum)).max()),
                   "raycounts equal GPU", np.array_equal(brc, res.raycount), "pixel", ba[wp[0]].tolist())
-            for alt in (dict(unpacked_nodes=1), dict(), dict(build_on_device=1), dict(unpacked_nodes=1, bvh_depth_cap=32)):
+            for alt in (dict(node_format=1), dict(node_format=2), dict(), dict(build_on_device=1), dict(node_format=1, bvh_depth_cap=32)):
                 ctx.set_tuning(**alt); ctx.upload_scene(triangles=tris, materials=s)
                 r2 = ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=chunk, **kw), want_raycount=True)
                 print("   variant", alt, "err", float(np.abs(np.nan_to_num(r2.accum) - np.nan_to_num(oa)).max()),
