@@ -117,7 +117,7 @@ typedef struct {
     uint32_t force_global_scene;  /* 1: never stage a small scene in LDS */
     uint32_t bvh_depth_cap;       /* BVH builders: cap on inner-node levels, 8..32 (host 24, device 32); applies to the NEXT rt_upload_scene */
     uint32_t build_on_device;     /* 1: the NEXT rt_upload_scene builds the tree on the GPU (Morton order; about 1.4 ms for 3e5
-                                   * triangles against 50 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
+                                   * triangles against 70 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
                                    * (C4 mesh) slower than on the host's SAH tree -- for scenes that change every frame) */
     uint32_t node_format;         /* tree nodes of the NEXT rt_upload_scene of a large triangle scene (host build): 0 = default (RT_NODES_WIDE),
                                    * RT_NODES_BINARY80 = two children, 80 bytes with a refs record; RT_NODES_BINARY72 = two children, 72
