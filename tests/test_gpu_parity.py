@@ -837,3 +837,27 @@ def test_render_and_write_ppm(gpu_ctx, tmp_path):
     b = np.loadtxt(g, skiprows=3, dtype=np.int64)
     assert open(f).read().split("\n")[:3] == ["P3", "%d %d" % (nx, ny), "255"]
     assert psnr_u8(a, b) >= MIN_PSNR
+
+
+def test_standalone_program_writes_the_same_image(gpu_ctx, tmp_path):
+    """raytrace_amd/host/rt_main: the C++ mirror of the reference's standalone main (raytracer.zig:714-745) -- book scene,
+    the reference's camera pose, P3 PPM out -- against the Python path on the same configuration (byte-equal pixels)
+    and against the oracle."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytrace_amd", "host", "rt_main")
+    assert os.path.exists(exe), "build it first: make -C raytrace_amd/csrc (__graft_entry__.build())"
+    nx, ny, spp = 160, 90, 4
+    f = str(tmp_path / "Scene.ppm")
+    out = subprocess.run([exe, str(nx), str(ny), str(spp), f], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "World contains 314 spheres" in out.stdout and "Creating %d x %d image" % (nx, ny) in out.stdout
+    assert open(f).read().split("\n")[:3] == ["P3", "%d %d" % (nx, ny), "255"]
+    a = np.loadtxt(f, skiprows=3, dtype=np.int64).reshape(-1, 3)
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    res = gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=R.RT_SPP_CHUNK_AUTO))
+    assert np.array_equal(a, res.rgb8.astype(np.int64))
+    w = O.World(spheres=spheres_to_oracle(s))
+    _, o8, _, _ = O.render_counter(w, ocam, O.make_config(nx, ny, spp))
+    assert psnr_u8(a, o8) >= MIN_PSNR
+    assert subprocess.run([exe, "0", "0", "1"], capture_output=True, timeout=60).returncode == 2
