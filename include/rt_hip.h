@@ -144,7 +144,8 @@ int  rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words);
 int rt_upload_scene(rt_ctx *ctx, const rt_spheres *spheres, const rt_triangles *triangles,
                     const rt_spheres *materials);
 
-/* What the last upload built (any pointer may be NULL). */
+/* What the last upload built (any pointer may be NULL).  n_bvh_nodes and bvh_depth describe the tree as uploaded: for a
+ * mesh in the default four-wide node format they count wide nodes and wide levels. */
 int rt_scene_info(const rt_ctx *ctx, uint32_t *n_spheres, uint32_t *n_triangles, uint32_t *n_bvh_nodes,
                   uint32_t *bvh_depth);
 /* Wall time of the last rt_upload_scene: repacking (+ BVH build + validation, when the host builds) on the host,
