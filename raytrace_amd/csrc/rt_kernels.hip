@@ -36,6 +36,9 @@ namespace {
 
 constexpr uint32_t NOPIX = 0xFFFFFFFFu;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;
+// the wave's lane mask of a predicate, taken straight from the compare's SGPR pair (HIP's __ballot goes through an integer
+// and costs a v_cndmask + v_cmp per use)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t DONE = 0xFFFFFFFFu;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr float    T_MAX = 3.402823466e+38f;   // std.math.floatMax(f32), raytracer.zig:555
@@ -48,7 +51,7 @@ enum : uint32_t { K_LAMBERTIAN = 0, K_METAL = 1, K_DIELECTRIC = 2 };
 __device__ __forceinline__ void prof_block(uint32_t *prof, int block)
 {
     if (prof) {
-        const unsigned long long m = __ballot(1);
+        const unsigned long long m = wave_ballot(1);
         if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&prof[2 * block], 1u);
         atomicAdd(&prof[2 * block + 1], 1u);
     }
@@ -102,7 +105,7 @@ __device__ __forceinline__ f3 sphere_normal(f3 pc, float4 ax, uint32_t *prof = n
     f3 n = mk(div_recip(pc.x, ax.x, ax.w), div_recip(pc.y, ax.x, ax.w), div_recip(pc.z, ax.x, ax.w));
     const float m = fminf(fminf(__builtin_fabsf(pc.x), __builtin_fabsf(pc.y)), __builtin_fabsf(pc.z));
     const bool slow = !(m >= 0x1.0p-100f) || !(ax.w == ax.w);
-    if (__ballot(slow) != 0ull) { prof_block(prof, RT_PB_NORMAL_SLOW); n = pc / ax.x; }
+    if (wave_ballot(slow) != 0ull) { prof_block(prof, RT_PB_NORMAL_SLOW); n = pc / ax.x; }
     return n;
 }
 
@@ -126,7 +129,7 @@ __device__ __forceinline__ bool scatter_ray(Lane &L, const Surface &S, f3 unit, 
         const float cs = u32_to_unit_float(r[3]);
         bool risky;
         float cb = cbrt_unit_fast(cs, risky);                      // bit-identical to cbrt_f32 on the unit grid
-        if (__ballot(risky) != 0ull) { prof_block(prof, RT_PB_CBRT_SLOW); cb = cbrt_f32(cs); }   // 1 input in 4096: musl's f64 steps decide
+        if (wave_ballot(risky) != 0ull) { prof_block(prof, RT_PB_CBRT_SLOW); cb = cbrt_f32(cs); }   // 1 input in 4096: musl's f64 steps decide
         const f3 rius = mk((2.0f * cn.x - 1.0f) * cb, (2.0f * cn.y - 1.0f) * cb, (2.0f * cn.z - 1.0f) * cb);
         if (S.kind == K_LAMBERTIAN) {                              // Lambertian.scatter, :438-445
             prof_block(prof, RT_PB_LAMBERTIAN);
@@ -274,7 +277,7 @@ __device__ __forceinline__ void ray_splat(RaySplat &R, f3 o, f3 d, float a, floa
     R.ex = R.ey = R.ez = (v2f){ 0.0f, -T_MAX };
     bool perp = false;
     const bool steep = !(xmax < 0.5f);                  // also NaN and infinity (a zero direction component)
-    if (__ballot(steep) != 0ull) {
+    if (wave_ballot(steep) != 0ull) {
         if (steep) {
             v2f e[3];
 #pragma unroll
@@ -390,7 +393,7 @@ __device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bo
         // wave's leader lane); the lanes that need an item take consecutive ones from it (ballot + popcount
         // rank), and only when the range runs dry does the leader reserve the next P.queue_batch items with ONE
         // atomic on the global head.  (One atomic per item saturates a single counter at this kernel's rate.)
-        const unsigned long long m = __ballot(1);
+        const unsigned long long m = wave_ballot(1);
         const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
         uint32_t q_next = 0, q_avail = 0, q_new = 0;
@@ -470,10 +473,10 @@ __device__ __forceinline__ bool advance_prefetch(const TraceParams &P, Lane &L, 
         O.my_rays += L.nrays;
         L.pix = NOPIX;
     }
-    if (__ballot(fin && L.nx_pix == NOPIX && !L.dry) != 0ull) {     // wave-uniform: refill every empty slot
+    if (wave_ballot(fin && L.nx_pix == NOPIX && !L.dry) != 0ull) {     // wave-uniform: refill every empty slot
         prof_block(prof, RT_PB_DEQUEUE);
         const bool take = L.nx_pix == NOPIX && !L.dry;
-        const unsigned long long m = __ballot(take);
+        const unsigned long long m = wave_ballot(take);
         const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
         uint32_t q_next = 0, q_avail = 0, q_new = 0;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) void rt_trace_brute_kernel(
             S.n = sphere_normal(S.p - mk(g.x, g.y, g.z), ax, prof);
             S.kind = __float_as_uint(ax.y); S.param = ax.z; S.albedo = mk(al.x, al.y, al.z); S.r0sq = al.w; S.inv_param = al2.x;
         });
-        if (__ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
+        if (wave_ballot(alive || has_ray) == 0ull) break;             // queue drained and nothing in flight
 
         // world.hit: closest root over all spheres in list order (raytracer.zig:92-113).  Lanes without a
         // ray run the loop on dummy data.
@@ -792,10 +795,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 
     for (;;) {
         // ---- lanes whose traversal is complete: exact tests, shade, next ray --------------------------
-        if (__ballot(node == DONE && (has_ray || alive)) != 0ull) {
+        if (wave_ballot(node == DONE && (has_ray || alive)) != 0ull) {
             // drain the queues of the finished lanes; lanes still traversing join each batch (their best_t tightens)
             if constexpr (SHARED_Q) { while (wcount != 0u) test_batch(); }
-            else { while (__ballot(node == DONE && ncand != 0u) != 0ull) test_one(); }
+            else { while (wave_ballot(node == DONE && ncand != 0u) != 0ull) test_one(); }
             if (HIST) c_wshade += 1;
             if (node == DONE) {
                 if (HIST && has_ray) c_lshade += 1;
@@ -829,8 +832,8 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 }
             }
         }
-        if (__ballot(alive || has_ray) == 0ull) break;         // queue drained and nothing in flight
-        wave_perp = __ballot(RS.perp && node != DONE) != 0ull;
+        if (wave_ballot(alive || has_ray) == 0ull) break;         // queue drained and nothing in flight
+        wave_perp = wave_ballot(RS.perp && node != DONE) != 0ull;
 
         // ---- traversal steps: every iteration is an inner-node visit for every traversing lane; hit
         //      leaves are only queued.  Two copies of the loop: the slab test's extra term (box2_hit_fma<true>)
@@ -900,12 +903,12 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned long long m = __ballot(push[k]);
+                    const unsigned long long m = wave_ballot(push[k]);
                     if (push[k]) wq[wcount + (uint32_t)__popcll(m & below)] = (lane << 26) | cand[k];
                     wcount += (uint32_t)__popcll(m);
                 }
                 while (wcount >= 64u) test_batch();
-                if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
+                if ((uint32_t)__popcll(wave_ballot(node != DONE)) < P.keep_traversing) break;
                 continue;
             }
             bool push0 = false, push1 = false;
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             if constexpr (SHARED_Q) {
                 // append this step's candidates behind the queue's tail (wave-wide prefix counts: no atomics), then run
                 // full batches
-                const unsigned long long m0 = __ballot(push0), m1 = __ballot(push1);
+                const unsigned long long m0 = wave_ballot(push0), m1 = wave_ballot(push1);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (push0) wq[wcount + (uint32_t)__popcll(m0 & below)] = (lane << 26) | cand0;
                 wcount += (uint32_t)__popcll(m0);
@@ -971,10 +974,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                 wcount += (uint32_t)__popcll(m1);
                 while (wcount >= 64u) test_batch();
             } else {
-                if ((uint32_t)__popcll(__ballot(ncand != 0u)) >= P.flush_lanes) test_one();
-                while (__ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
+                if ((uint32_t)__popcll(wave_ballot(ncand != 0u)) >= P.flush_lanes) test_one();
+                while (wave_ballot(ncand > (uint32_t)(CAND - 2)) != 0ull) test_one();
             }
-            if ((uint32_t)__popcll(__ballot(node != DONE)) < P.keep_traversing) break;
+            if ((uint32_t)__popcll(wave_ballot(node != DONE)) < P.keep_traversing) break;
         }
         };
         if (wave_perp) traverse(std::true_type{}); else traverse(std::false_type{});
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(256) void rt_selftest_cbrt_grid_kernel(float *out, 
     const float x = u32_to_unit_float(k << 8);
     bool risky;
     float cb = cbrt_unit_fast(x, risky);
-    if (__ballot(risky) != 0ull) cb = cbrt_f32(x);
+    if (wave_ballot(risky) != 0ull) cb = cbrt_f32(x);
     if (risky) atomicAdd(n_risky, 1ull);
     out[k] = cb;
 }
