@@ -887,15 +887,25 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                       key[i] = sw ? kj : ki; key[j] = sw ? ki : kj; ref[i] = sw ? rj : ri; ref[j] = sw ? ri : rj; }
                     RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-                    if (nv > 3u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[3]; sp += 1; }
-                    if (nv > 2u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[2]; sp += 1; }
-                    if (nv > 1u) { s_stack[sp * BLOCK + tid] = (idx_t)ref[1]; sp += 1; }
+                    // A stacked entry carries, above its 24-bit ref, an 8-bit code of the box's entry distance (a monotonic,
+                    // clamped cut of the float's exponent and top three mantissa bits): when the entry is popped and the code
+                    // is ABOVE the code of the closest hit found since, the whole subtree lies behind that hit and is dropped
+                    // unvisited.  code(a) > code(b) implies a > b, so nothing that could still hold a closer hit is dropped.
+                    auto dist_code = [](float t) {           // t >= 0
+                        const int q = (int)(__float_as_uint(t) >> 20) - (111 << 3);      // 0 at 2^-16, 255 just below 2^16
+                        return (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+                    };
+                    if (nv > 3u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[3] | (dist_code(key[3]) << 24)); sp += 1; }
+                    if (nv > 2u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[2] | (dist_code(key[2]) << 24)); sp += 1; }
+                    if (nv > 1u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[1] | (dist_code(key[1]) << 24)); sp += 1; }
                     const uint32_t near_c = nv > 0u ? ref[0] : DONE;
                     if (near_c != DONE) {
                         node = near_c;
                     } else if (sp > 0) {
-                        sp -= 1;
-                        node = s_stack[sp * BLOCK + tid];
+                        const uint32_t best_code = dist_code(best_t);
+                        uint32_t e;
+                        do { sp -= 1; e = s_stack[sp * BLOCK + tid]; } while ((e >> 24) > best_code && sp > 0);
+                        node = (e >> 24) > best_code ? DONE : (e & 0x00FFFFFFu);
                     } else {
                         node = DONE;
                     }
