@@ -49,8 +49,12 @@ if "TCP_TOTAL_CACHE_ACCESSES_sum" in agg and "GRBM_GUI_ACTIVE" in agg:
     d["l1_hit_rate"] = 1.0 - agg["TCP_TCC_READ_REQ_sum"] / agg["TCP_TOTAL_CACHE_ACCESSES_sum"]
     d["l1_requests_per_ray"] = agg["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays
 if "SQ_INSTS_VALU" in agg and "GRBM_GUI_ACTIVE" in agg:
-    # a wave64 VALU instruction holds its SIMD-32 for 2 cycles (MI355X_MICROARCH.md); 4 SIMDs per CU
-    d["valu_issue_busy"] = agg["SQ_INSTS_VALU"] * 2 / (agg["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
+    # What the 1 024 SIMDs issue, against what they were MEASURED to issue (tools/ubench/valu_rate.hip, 8 waves per
+    # SIMD, independent instructions): v_fma_f32 1.74 ns per wave-instruction and SIMD, v_cmp + v_cndmask 1.67,
+    # v_mul_f32 1.21, v_pk_fma_f32 2.12.  The nominal rate (2 cycles on a SIMD-32 = 0.83 ns) was not reached by any
+    # of them; 1.7 ns is the yardstick for this instruction mix.
+    d["valu_ns_per_inst_per_simd"] = bench["roofline"]["kernel_ms"] * 1e6 * 1024 / agg["SQ_INSTS_VALU"]
+    d["valu_issue_vs_measured_rate"] = 1.7 / d["valu_ns_per_inst_per_simd"]
 out = {"workload": bench["config"]["workload"], "dispatch": info, "counters_one_launch": dict(agg), "derived": d,
        "bench": {k: bench[k] for k in ("value", "ms_per_step")}, "roofline": bench["roofline"]}
 json.dump(out, open("profiles/%s_pmc.json" % name, "w"), indent=1)
