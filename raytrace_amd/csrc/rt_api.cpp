@@ -568,7 +568,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         const uint32_t fmt = ctx->tuning.node_format ? ctx->tuning.node_format : RT_NODES_WIDE;
         const bool want_wide = have_tri && !device_build && fmt == RT_NODES_WIDE && n_prim >= 1024u && n_prim <= (1u << 22) &&
                                (!ctx->tuning.bvh_depth_cap || ctx->tuning.node_format == RT_NODES_WIDE);   // (an explicit cap asks for a binary tree of that depth)
-        const int depth_cap = want_wide ? 22 : ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
+        const int depth_cap = want_wide ? std::min(22, ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 22) : ctx->tuning.bvh_depth_cap ? (int)ctx->tuning.bvh_depth_cap : 24;   // 24-entry stacks: 5 workgroups per CU instead of 3
         const rtbvh::Tree tree = device_build ? rtbvh::Tree() : rtbvh::build(prims, depth_cap);
         if (!device_build && !rtbvh::validate(tree, prims)) return RT_E_STATE;   // NaN/inf geometry ends here, not on the GPU
         // host tree (64-byte nodes: lo0, hi0, lo1, hi1, refs) -> device nodes (RT_NODE_BYTES, rt_kernels.h)

@@ -51,7 +51,7 @@ constexpr uint32_t RT_PACKED_LEAF_BIT = 0x800000u;
 // {near0..near3, far0..far3}.  Refs as in the packed node (24 bits in the low mantissa bytes of the child's planes;
 // inner = index of a wide node).  A missing child has lo = +inf, hi = -inf (never hit) and a zero ref.
 constexpr int RT_WIDE_NODE_BYTES = 144;
-constexpr int RT_WIDE_STACK = 32;        // 3 pushes per level: trees of at most 11 wide levels (binary depth cap 22)
+constexpr int RT_WIDE_STACK = 34;        // 3 pushes per level, leaves included: trees of at most 11 wide levels (binary depth cap 22)
 
 struct DeviceScene {
     const float4 *geom = nullptr;

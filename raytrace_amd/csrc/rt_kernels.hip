@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     //              the owner's (t, index) word with an LDS atomic min -- so the expensive test runs with full waves
     //              although a ray meets only three or four leaves on ~30 steps (the per-lane form filled 31 % of it)
     constexpr bool SHARED_Q = KIND == KIND_BVH_TRIANGLES;
-    constexpr int  WQ_CAP = 64 + (WIDE ? 4 : 2) * 64; // at most 63 left over + two (WIDE: four) candidates per lane and step
+    constexpr int  WQ_CAP = 64 + (WIDE ? 1 : 2) * 64; // at most 63 left over + two (WIDE: one) candidates per lane and step
     __shared__ idx_t s_cand[SHARED_Q ? 1 : CAND * BLOCK];
     __shared__ uint32_t s_wcand[SHARED_Q ? (NT / 64) * WQ_CAP : 1];
     __shared__ unsigned long long s_wbest[SHARED_Q ? NT : 1];      // per lane: bits(t) << 32 | triangle: min = closest, ties to the lower index
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
         const uint32_t n = wcount < 64u ? wcount : 64u, base = wcount - n;
         const bool mine = lane < n;
         const uint32_t e = mine ? wq[base + lane] : (lane << 26);
-        const uint32_t owner = e >> 26, prim = e & 0x03FFFFFFu;
+        const uint32_t owner = e >> 26, prim = e & (WIDE ? 0x007FFFFFu : 0x03FFFFFFu);    // WIDE entries still carry the ref's leaf bit
         // the owner's ray (every lane takes part in the shuffles: a lane's registers are read by others)
         Lane R;
         R.o = mk(__shfl(L.o.x, (int)owner), __shfl(L.o.y, (int)owner), __shfl(L.o.z, (int)owner));
@@ -838,14 +838,22 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
         // ---- traversal steps: every iteration is an inner-node visit for every traversing lane; hit
         //      leaves are only queued.  Two copies of the loop: the slab test's extra term (box2_hit_fma<true>)
         //      runs only in a traversal phase in which some lane needs it.
+        // WIDE: a stack entry carries, above its 24-bit ref, an 8-bit code of the box's entry distance (a monotonic,
+        // clamped cut of the float's exponent and top three mantissa bits)
+        auto dist_code = [](float t) {           // t >= 0
+            const int q = (int)(__float_as_uint(t) >> 20) - (111 << 3);      // 0 at 2^-16, 255 just below 2^16
+            return (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        };
         auto traverse = [&](auto perp_tag) {
         constexpr bool PERP = decltype(perp_tag)::value;
         for (;;) {
             if (HIST) c_wsteps += 1;
             if constexpr (WIDE) {
-                bool push[4] = { false, false, false, false };
-                uint32_t cand[4] = { 0, 0, 0, 0 };
-                if (node != DONE) {
+                constexpr uint32_t POP = 0xFFFFFFFEu;             // "take the next entry off the stack" (never survives a step)
+                // ---- the lane's node is an inner node: test its four child boxes; ALL hit children, leaves included, are
+                //      sorted by entry distance (five compare-exchanges; a miss or a missing child sorts behind everything),
+                //      the nearest becomes the lane's node and the others go on the stack farthest first
+                if (node < RT_PACKED_LEAF_BIT) {
                     if (HIST) c_lsteps += 1;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const char *const nbase = (const char *)bvh;
@@ -853,11 +861,11 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     const v4f xn = *(const v4f *)(nbase + (noff + RS.ox)), xf = *(const v4f *)(nbase + (noff + RS.ox + 16u));
                     const v4f yn = *(const v4f *)(nbase + (noff + RS.oy)), yf = *(const v4f *)(nbase + (noff + RS.oy + 16u));
                     const v4f zn = *(const v4f *)(nbase + (noff + RS.oz)), zf = *(const v4f *)(nbase + (noff + RS.oz + 16u));
-                    uint32_t c[4];
+                    uint32_t ref[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t xy = __builtin_amdgcn_perm(__float_as_uint(yn[k]), __float_as_uint(xn[k]), 0x0c0c0400u);
-                        c[k] = __builtin_amdgcn_perm(__float_as_uint(zn[k]), xy, 0x0c040100u);
+                        ref[k] = __builtin_amdgcn_perm(__float_as_uint(zn[k]), xy, 0x0c040100u);
                     }
                     float tn[4], tf[4];
                     {
@@ -870,52 +878,37 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                                          pz = { (v2f){ zn.z, zn.w }, (v2f){ zf.z, zf.w } };
                         box2_hit_fma<PERP>(px, py, pz, RS, t_min_v, best_t, tn[2], tn[3], tf[2], tf[3]);
                     }
-                    // hit inner children sorted by entry distance (five compare-exchanges): descend into the nearest, stack the
-                    // others farthest first (missing children never hit; a leaf or a miss sorts behind everything)
                     float key[4];
-                    uint32_t ref[4];
-                    uint32_t nv = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool h = tn[k] <= tf[k], l = (c[k] & RT_PACKED_LEAF_BIT) != 0u;
-                        push[k] = h && l; cand[k] = c[k] & ~RT_PACKED_LEAF_BIT;
-                        const bool v = h && !l;
-                        key[k] = v ? tn[k] : __builtin_inff(); ref[k] = c[k];
-                        nv += v ? 1u : 0u;
-                    }
+                    for (int k = 0; k < 4; ++k) key[k] = tn[k] <= tf[k] ? tn[k] : __builtin_inff();     // (entry distances are finite)
 #define RT_CE(i, j) { const bool sw = key[j] < key[i]; const float ki = key[i], kj = key[j]; const uint32_t ri = ref[i], rj = ref[j]; \
                       key[i] = sw ? kj : ki; key[j] = sw ? ki : kj; ref[i] = sw ? rj : ri; ref[j] = sw ? ri : rj; }
                     RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-                    // A stacked entry carries, above its 24-bit ref, an 8-bit code of the box's entry distance (a monotonic,
-                    // clamped cut of the float's exponent and top three mantissa bits): when the entry is popped and the code
-                    // is ABOVE the code of the closest hit found since, the whole subtree lies behind that hit and is dropped
-                    // unvisited.  code(a) > code(b) implies a > b, so nothing that could still hold a closer hit is dropped.
-                    auto dist_code = [](float t) {           // t >= 0
-                        const int q = (int)(__float_as_uint(t) >> 20) - (111 << 3);      // 0 at 2^-16, 255 just below 2^16
-                        return (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
-                    };
-                    if (nv > 3u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[3] | (dist_code(key[3]) << 24)); sp += 1; }
-                    if (nv > 2u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[2] | (dist_code(key[2]) << 24)); sp += 1; }
-                    if (nv > 1u) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[1] | (dist_code(key[1]) << 24)); sp += 1; }
-                    const uint32_t near_c = nv > 0u ? ref[0] : DONE;
-                    if (near_c != DONE) {
-                        node = near_c;
-                    } else if (sp > 0) {
+                    if (key[3] < __builtin_inff()) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[3] | (dist_code(key[3]) << 24)); sp += 1; }
+                    if (key[2] < __builtin_inff()) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[2] | (dist_code(key[2]) << 24)); sp += 1; }
+                    if (key[1] < __builtin_inff()) { s_stack[sp * BLOCK + tid] = (idx_t)(ref[1] | (dist_code(key[1]) << 24)); sp += 1; }
+                    node = key[0] < __builtin_inff() ? ref[0] : POP;
+                }
+                // ---- the lane's node is a leaf (just chosen as the nearest child, or popped in the step before): its
+                //      triangle joins the wave's queue (the entry keeps the ref's leaf bit; test_batch drops it)
+                const bool at_leaf = node - RT_PACKED_LEAF_BIT < RT_PACKED_LEAF_BIT;          // refs 2^23 .. 2^24 - 1
+                {
+                    const unsigned long long m = wave_ballot(at_leaf);
+                    if (at_leaf) wq[wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (lane << 26) | node;
+                    wcount += (uint32_t)__popcll(m);
+                }
+                // ---- next node off the stack.  An entry whose distance code is ABOVE the code of the closest hit found
+                //      since it was pushed lies behind that hit with its whole subtree (or its triangle) and is dropped:
+                //      code(a) > code(b) implies a > b, so nothing that could still hold a closer hit is dropped.
+                if (at_leaf || node == POP) {
+                    node = DONE;
+                    if (sp > 0) {
                         const uint32_t best_code = dist_code(best_t);
                         uint32_t e;
                         do { sp -= 1; e = s_stack[sp * BLOCK + tid]; } while ((e >> 24) > best_code && sp > 0);
-                        node = (e >> 24) > best_code ? DONE : (e & 0x00FFFFFFu);
-                    } else {
-                        node = DONE;
+                        if ((e >> 24) <= best_code) node = e & 0x00FFFFFFu;
                     }
-                }
-                const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned long long m = wave_ballot(push[k]);
-                    if (push[k]) wq[wcount + (uint32_t)__popcll(m & below)] = (lane << 26) | cand[k];
-                    wcount += (uint32_t)__popcll(m);
                 }
                 while (wcount >= 64u) test_batch();
                 if ((uint32_t)__popcll(wave_ballot(node != DONE)) < P.keep_traversing) break;
