@@ -45,7 +45,7 @@ constexpr int RT_NODE_BYTES = 80;
 // of the ref in BOTH lo_c and hi_c of axis k (x, y, z), planes rounded outward to the next float carrying that byte.
 constexpr int RT_PACKED_NODE_BYTES = 72;
 constexpr uint32_t RT_PACKED_LEAF_BIT = 0x800000u;
-// Wide node of large triangle scenes (rt_tuning.wide_nodes), 144 bytes: two levels of the binary tree collapsed into one
+// Wide node of large triangle scenes (rt_tuning.node_format = RT_NODES_WIDE, the default for large meshes), 144 bytes: two levels of the binary tree collapsed into one
 // node of up to four children -- half as many dependent node fetches per ray.  Per axis (48 bytes)
 // {hi0..hi3, lo0..lo3, hi0..hi3}: a lane reads 32 bytes at +16 (ray runs up the axis) or +0 (down) and gets
 // {near0..near3, far0..far3}.  Refs as in the packed node (24 bits in the low mantissa bytes of the child's planes;
