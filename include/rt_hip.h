@@ -115,7 +115,8 @@ typedef struct {
     uint32_t flush_lanes;         /* BVH kernels: run a batch of exact tests when this many lanes hold a candidate: 1..65 (24) */
     uint32_t keep_traversing;     /* BVH kernels: leave the traversal loop when fewer lanes than this traverse: 1..64 (8; triangles 16) */
     uint32_t force_global_scene;  /* 1: never stage a small scene in LDS */
-    uint32_t bvh_depth_cap;       /* BVH builders: cap on inner-node levels, 8..32 (host 24, device 32); applies to the NEXT rt_upload_scene */
+    uint32_t bvh_depth_cap;       /* BVH builders: cap on inner-node levels, 8..32 (host 24, device 32; under RT_NODES_WIDE the binary
+                                   * tree that is collapsed: 22, an explicit cap only lowers it); applies to the NEXT rt_upload_scene */
     uint32_t build_on_device;     /* 1: the NEXT rt_upload_scene builds the tree on the GPU (Morton order; about 1.4 ms for 3e5
                                    * triangles against 70 ms on the host, but the trace on it runs 1.15x (book spheres) to 3x
                                    * (C4 mesh) slower than on the host's SAH tree -- for scenes that change every frame) */
