@@ -3,9 +3,14 @@
 //! Binds include/rt_hip.h (librt_hip.so) and offers replacements with the reference's own signatures:
 //!   render_and_write_hip  for rt.render_and_write   (raytracer.zig:580-633; call sites main.zig:317, raytracer.zig:742)
 //!   start_trace_hip       for main.zig's start_trace (main.zig:307-318), progressive: the window keeps drawing
-//! Shipped as source: this image has no Zig toolchain, so the file is NOT compiled or tested here; the same ABI is
-//! exercised from Python (ctypes) and C++ by the test suite.  build.zig: exe.addLibraryPath(...);
+//! Shipped as source: this image has no Zig toolchain, so the file is NOT compiled here; the same ABI is exercised
+//! from Python (ctypes) and C++ by the test suite.  build.zig: exe.addLibraryPath(...);
 //! exe.linkSystemLibrary("rt_hip"); exe.linkLibC();
+//! It touches the reference only through declarations that ARE `pub` there -- rt.Hittable (raytracer.zig:712),
+//! rt.cam (:710), img_io.ImgType / Image_s / write_ppm_image (image.zig:6,12,18) -- so the reference's files stay
+//! unmodified: `Sphere` (:38) and `shape_s` (:26) are private to raytracer.zig, hence `objects: anytype` and the
+//! local `Shape` below (an anonymous `.{ .nx = .., .ny = .. }` literal, as both reference call sites pass, coerces
+//! to it).  tests/test_zig_shim.py checks every `rt.` / `img_io.` name used here against that list.
 const std = @import("std");
 const rt = @import("raytracer.zig");
 const img_io = @import("image.zig");
@@ -75,6 +80,9 @@ extern fn rt_tessellate_spheres(spheres: *const rt_spheres, slices: c_int, stack
 
 pub const HipError = error{HipBackend};
 
+/// raytracer.zig:26-29 `shape_s` (private there): same fields, same order.
+pub const Shape = struct { ny: usize, nx: usize };
+
 fn check(code: c_int) HipError!void {
     if (code < 0) {
         std.log.err("rt_hip: {s}", .{rt_strerror(code)});
@@ -95,7 +103,7 @@ const SphereSoA = struct {
     b: []f32,
     par: []f32,
 
-    fn init(a: std.mem.Allocator, objects: []const rt.Sphere) !SphereSoA {
+    fn init(a: std.mem.Allocator, objects: anytype) !SphereSoA { // []const Sphere; the element type is private to raytracer.zig
         const n = objects.len;
         var s = SphereSoA{
             .cx = try a.alloc(f32, n), .cy = try a.alloc(f32, n), .cz = try a.alloc(f32, n), .rad = try a.alloc(f32, n),
@@ -126,12 +134,12 @@ fn cameraOf(c: anytype) rt_camera {
     return .{ .lower_left = c.lower_left, .horizontal = c.horizontal, .vertical = c.vertical, .origin = c.origin, .subtract_origin = 1 };
 }
 
-fn configOf(shape: anytype, num_samples: u32) rt_config {
+fn configOf(shape: Shape, num_samples: u32) rt_config {
     return .{ .nx = @intCast(shape.nx), .ny = @intCast(shape.ny), .spp_begin = 0, .spp_end = num_samples,
               .spp_total = num_samples, .max_depth = 16, .t_min = 0.001, .seed = 1 };
 }
 
-fn writeImage(a: std.mem.Allocator, fname: []const u8, img: []const u8, shape: anytype, filetype: img_io.ImgType) !void {
+fn writeImage(a: std.mem.Allocator, fname: []const u8, img: []const u8, shape: Shape, filetype: img_io.ImgType) !void {
     if (filetype != .ppm) return;
     const n = shape.nx * shape.ny;
     var list = try std.ArrayList(@Vector(3, u8)).initCapacity(a, n);
@@ -143,7 +151,7 @@ fn writeImage(a: std.mem.Allocator, fname: []const u8, img: []const u8, shape: a
 /// Same signature as rt.render_and_write.  num_samples is the TOTAL per pixel (the reference renders num_samples
 /// on each of getCpuCount() threads).  Uses every GPU of the node: the reference's `for (0..n_cpu) Thread.spawn`
 /// (raytracer.zig:594-601) with GPUs for threads, joined by one RCCL reduce inside rt_render_multi.
-pub fn render_and_write_hip(fname: []const u8, num_samples: u16, world: rt.Hittable, shape: anytype,
+pub fn render_and_write_hip(fname: []const u8, num_samples: u16, world: rt.Hittable, shape: Shape,
                             filetype: img_io.ImgType, allocator: std.mem.Allocator) !void {
     var arena = std.heap.ArenaAllocator.init(allocator);
     defer arena.deinit();
@@ -171,7 +179,7 @@ pub fn render_and_write_hip(fname: []const u8, num_samples: u16, world: rt.Hitta
 /// The reference's own output rule (quirk Q4: the integer mean of n_images gamma'd u8 images keyed i*123,
 /// raytracer.zig:600,610-617) for an A/B against a CPU render; n_images plays getCpuCount().
 pub fn render_and_write_reference_style(fname: []const u8, num_samples: u16, n_images: u32, world: rt.Hittable,
-                                        shape: anytype, filetype: img_io.ImgType, allocator: std.mem.Allocator) !void {
+                                        shape: Shape, filetype: img_io.ImgType, allocator: std.mem.Allocator) !void {
     var arena = std.heap.ArenaAllocator.init(allocator);
     defer arena.deinit();
     const a = arena.allocator();
@@ -189,7 +197,7 @@ pub fn render_and_write_reference_style(fname: []const u8, num_samples: u16, n_i
 }
 
 /// The preview's triangle meshes (zmesh parametric spheres, main.zig:128-138) traced instead of rasterised.
-pub fn render_mesh_and_write_hip(fname: []const u8, num_samples: u16, world: rt.Hittable, shape: anytype,
+pub fn render_mesh_and_write_hip(fname: []const u8, num_samples: u16, world: rt.Hittable, shape: Shape,
                                  filetype: img_io.ImgType, allocator: std.mem.Allocator) !void {
     var arena = std.heap.ArenaAllocator.init(allocator);
     defer arena.deinit();
@@ -224,7 +232,7 @@ pub fn render_mesh_and_write_hip(fname: []const u8, num_samples: u16, world: rt.
 pub const TraceJob = struct {
     ctx: ?*rt_ctx = null,
     rgb8: []u8 = &.{},
-    shape: rt.shape_s = undefined,
+    shape: Shape = undefined,
     spp_done: u32 = 0,
     active: bool = false,
 
