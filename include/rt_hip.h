@@ -134,9 +134,15 @@ int  rt_set_tuning(rt_ctx *ctx, const rt_tuning *tuning);   /* NULL = all defaul
 /* Restrict the ctx's own stream to a subset of the GPU's compute units (hipExtStreamCreateWithCUMask; bit i of
  * mask[] = CU i; on MI355X bit i lies on XCD i % 8) and size the persistent grid for that many CUs; NULL restores
  * the whole GPU.  No reference counterpart: it produces the "@1/8 GPU" figure of BASELINE.json's metric (32 CUs,
- * 19.66 TFLOP/s of FP32 vector peak).  Renders on a caller-supplied stream are not affected.  Note (ROCm 7.2): a
- * mask that leaves an XCD without any CU crashes inside the HIP runtime; keep at least one CU per XCD. */
+ * 19.66 TFLOP/s of FP32 vector peak).  Renders on a caller-supplied stream are not affected.
+ * The mask must keep at least one CU on EVERY one of the 8 XCDs: under ROCm 7.2 a mask that empties an XCD takes the
+ * process down inside the HIP runtime (as a stream mask and as HSA_CU_MASK alike), so such a mask -- e.g.
+ * {0x01010101}, "one XCD", or the first n < 8 CUs -- is rejected with RT_E_ARG before any HIP call is made, as is a
+ * mask that names no CU the device has.  A progressive render in flight on the ctx ends (its stream is replaced). */
 int  rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words);
+/* The argument check of rt_set_cu_mask by itself (pure host arithmetic, no GPU needed; no reference counterpart): the
+ * number of CUs of a device_cus-CU GPU the mask selects, or RT_E_ARG for a mask rt_set_cu_mask refuses. */
+int  rt_check_cu_mask(const uint32_t *mask, uint32_t n_words, uint32_t device_cus);
 
 /* ---- scene upload: the `world: Hittable` argument of Render (raytracer.zig:517) ------------- */
 /* Exactly one of spheres / triangles per scene; `materials` (kind, r, g, b, param) is required with
@@ -164,7 +170,8 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6]);
 int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out);
 /* Test aid, no reference counterpart, host arithmetic only (no GPU needed): the plane rounding of the packed tree nodes
  * (rt_tuning.node_format) -- the largest float <= v (down != 0) or the smallest float >= v (down == 0) whose low
- * mantissa byte equals payload (0..255). */
+ * mantissa byte equals payload (0..255); NaN when no finite float qualifies (v infinite, NaN, or within 256 floats of
+ * +-FLT_MAX on the outward side): rt_upload_scene then refuses the scene (RT_E_STATE) instead of packing a wrong ref. */
 float rt_debug_round_plane(float v, uint32_t payload, int down);
 /* Name of the trace kernel the last render launched (for profiles). */
 const char *rt_last_kernel_name(const rt_ctx *ctx);

@@ -54,7 +54,7 @@ class rt_stats(C.Structure):
 
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_last_rccl_error", "rt_selftest_rccl", "rt_set_flags", "rt_set_tuning", "rt_set_cu_mask", "rt_upload_scene",
+    "rt_create", "rt_destroy", "rt_strerror", "rt_last_hip_error", "rt_last_rccl_error", "rt_selftest_rccl", "rt_set_flags", "rt_set_tuning", "rt_set_cu_mask", "rt_check_cu_mask", "rt_upload_scene",
     "rt_scene_info", "rt_upload_timing", "rt_last_kernel_name", "rt_debug_wave_fill", "rt_debug_block_counts", "rt_debug_round_plane",
     "rt_device_count", "rt_render", "rt_render_multi", "rt_render_reference_style", "rt_progressive_begin", "rt_progressive_step", "rt_render_device", "rt_render_device_noalloc", "rt_tonemap_device", "rt_camera_basic", "rt_camera_set_position",
     "rt_random_scene", "rt_two_sphere_scene", "rt_tessellate_spheres", "rt_write_ppm", "rt_render_and_write",
@@ -97,6 +97,8 @@ def load():
     L.rt_set_tuning.restype = C.c_int
     L.rt_set_cu_mask.argtypes = [vp, u32p, C.c_uint32]
     L.rt_set_cu_mask.restype = C.c_int
+    L.rt_check_cu_mask.argtypes = [u32p, C.c_uint32, C.c_uint32]
+    L.rt_check_cu_mask.restype = C.c_int
     L.rt_upload_scene.argtypes = [vp, C.POINTER(rt_spheres), C.POINTER(rt_triangles), C.POINTER(rt_spheres)]
     L.rt_upload_scene.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, u32p, u32p, u32p, u32p]

@@ -240,10 +240,18 @@ class Context:
         if n_cus is None:
             self._check(self._L.rt_set_cu_mask(self._h, None, 0), "rt_set_cu_mask")
             return
+        if n_cus < 8:
+            # fewer than 8 leading bits leave an XCD without a CU; the library refuses such a mask too (RT_E_ARG)
+            raise ValueError("set_cu_mask: at least 8 CUs (one per XCD), got %d" % n_cus)
         words = (n_cus + 31) // 32
         mask = (C.c_uint32 * words)(*[0xFFFFFFFF if (w + 1) * 32 <= n_cus else (1 << (n_cus - w * 32)) - 1
                                       for w in range(words)])
         self._check(self._L.rt_set_cu_mask(self._h, mask, words), "rt_set_cu_mask")
+
+    def set_cu_mask_words(self, words):
+        """rt_set_cu_mask with an explicit mask (list of 32-bit words, bit i = CU i)."""
+        mask = (C.c_uint32 * len(words))(*words)
+        self._check(self._L.rt_set_cu_mask(self._h, mask, len(words)), "rt_set_cu_mask")
 
     def upload_scene(self, spheres=None, triangles=None, materials=None):
         sv = spheres.view() if spheres is not None else None

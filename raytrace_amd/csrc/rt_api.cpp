@@ -22,7 +22,8 @@
 
 struct rt_ctx {
     int          device = 0;
-    int          num_cus = 0;
+    int          num_cus = 0;                     // CUs the ctx's stream may use (rt_set_cu_mask)
+    int          device_cus = 0;                  // CUs of the GPU
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;
     uint32_t     flags = 0;
@@ -394,7 +395,7 @@ int rt_create(int device, rt_ctx **out)
         if ((e = hipSetDevice(device)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
-        ctx->num_cus = prop.multiProcessorCount;
+        ctx->num_cus = ctx->device_cus = prop.multiProcessorCount;
         if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
         if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
         if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) { ctx->last_hip = e; rc = RT_E_HIP; break; }
@@ -446,24 +447,43 @@ int rt_set_flags(rt_ctx *ctx, uint32_t flags)
     return RT_OK;
 }
 
+// gfx950 (MI355X): 8 XCDs; bit i of a HIP CU mask lies on XCD i % 8 (tools/ubench/cu_mask_probe.hip).
+constexpr uint32_t RT_XCDS = 8;
+
+// Pure argument check of rt_set_cu_mask (no HIP call): the number of usable CUs in the mask, or RT_E_ARG when the
+// mask is empty, names only CUs the device does not have, or leaves one of the 8 XCDs without a CU -- the ROCm 7.2
+// runtime dies inside hipExtStreamCreateWithCUMask / the first launch on such a stream, so that mask
+// must never reach HIP.
+int rt_check_cu_mask(const uint32_t *mask, uint32_t n_words, uint32_t device_cus)
+{
+    if (!mask || n_words == 0 || n_words > 64 || device_cus == 0) return RT_E_ARG;
+    uint32_t per_xcd[RT_XCDS] = { 0 };
+    int cus = 0;
+    for (uint32_t w = 0; w < n_words; ++w)
+        for (uint32_t b = 0; b < 32; ++b) {
+            const uint32_t cu = w * 32 + b;
+            if (cu < device_cus && ((mask[w] >> b) & 1u)) { per_xcd[cu % RT_XCDS]++; cus++; }
+        }
+    if (cus == 0) return RT_E_ARG;
+    if (device_cus >= RT_XCDS)
+        for (uint32_t x = 0; x < RT_XCDS; ++x)
+            if (per_xcd[x] == 0) return RT_E_ARG;
+    return cus;
+}
+
 int rt_set_cu_mask(rt_ctx *ctx, const uint32_t *mask, uint32_t n_words)
 {
     if (!ctx || (mask && (n_words == 0 || n_words > 64))) return RT_E_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    int cus = prop.multiProcessorCount;
-    hipStream_t st = nullptr;
-    if (mask) {
-        cus = 0;
-        for (uint32_t w = 0; w < n_words; ++w)
-            for (uint32_t b = 0; b < 32; ++b)
-                if (w * 32 + b < (uint32_t)prop.multiProcessorCount && ((mask[w] >> b) & 1u)) cus++;
-        if (cus == 0) return RT_E_ARG;
-        HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&st, n_words, mask));
-    } else {
-        HIP_TRY(ctx, hipStreamCreate(&st));
+    int cus = ctx->device_cus;
+    if (mask) {                       // checked before any HIP call
+        cus = rt_check_cu_mask(mask, n_words, (uint32_t)ctx->device_cus);
+        if (cus < 0) return cus;
     }
+    ctx->prog_active = false;         // a progressive render in flight ends here (its stream goes away)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    if (mask) HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&st, n_words, mask));
+    else HIP_TRY(ctx, hipStreamCreate(&st));
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     ctx->stream = st;
     ctx->num_cus = cus;          // the persistent grid is sized for the CUs the stream may use
@@ -501,6 +521,16 @@ static float with_low_byte(float v, uint32_t payload, bool down)
         else b -= 0x100u;
     }
     return -INFINITY;
+}
+
+// with_low_byte for a node plane, checked: false when the result is not a finite float carrying the payload (planes at
+// +-inf, NaN, or in the last block of 256 floats below FLT_MAX have no outward neighbour with that byte) -- the child
+// ref would then be garbage and the kernel would index the node array with it.
+static bool pack_plane(float v, uint32_t payload, bool down, float &out)
+{
+    out = with_low_byte(v, payload, down);
+    uint32_t b; std::memcpy(&b, &out, 4);
+    return std::isfinite(out) && (b & 0xFFu) == payload && (down ? out <= v : out >= v);
 }
 
 static int upload_vec(rt_ctx *ctx, float4 *&dst, const std::vector<float4> &src)
@@ -616,7 +646,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                         float l = inf, h = -inf;
                         if (c < nc) {
                             const uint32_t b = (packed_ref[c] >> (8 * ax)) & 0xFFu;
-                            l = with_low_byte(lo[c][ax], b, true); h = with_low_byte(hi[c][ax], b, false);
+                            if (!pack_plane(lo[c][ax], b, true, l) || !pack_plane(hi[c][ax], b, false, h)) return RT_E_STATE;
                         }
                         a[c] = h; a[4 + c] = l; a[8 + c] = h;
                     }
@@ -639,8 +669,9 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             }
             for (int ax = 0; ax < 3; ++ax) {
                 const uint32_t b0 = (ref[0] >> (8 * ax)) & 0xFFu, b1 = (ref[1] >> (8 * ax)) & 0xFFu;
-                const float lo0 = with_low_byte(w[ax], b0, true), hi0 = with_low_byte(w[3 + ax], b0, false);
-                const float lo1 = with_low_byte(w[6 + ax], b1, true), hi1 = with_low_byte(w[9 + ax], b1, false);
+                float lo0, hi0, lo1, hi1;
+                if (!pack_plane(w[ax], b0, true, lo0) || !pack_plane(w[3 + ax], b0, false, hi0) ||
+                    !pack_plane(w[6 + ax], b1, true, lo1) || !pack_plane(w[9 + ax], b1, false, hi1)) return RT_E_STATE;
                 float *a = d + 6 * ax;
                 a[0] = hi0; a[1] = hi1; a[2] = lo0; a[3] = lo1; a[4] = hi0; a[5] = hi1;
             }
@@ -662,6 +693,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         }
 
         const auto t_built = std::chrono::steady_clock::now();
+        ctx->prog_active = false;         // a progressive render of the old scene ends here
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_albedo);
@@ -705,7 +737,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
         const auto t_end = std::chrono::steady_clock::now();
         ctx->upload_build_ms = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
         ctx->upload_copy_ms = std::chrono::duration<double, std::milli>(t_copied - t_built).count();
-        ctx->upload_device_build_ms = std::chrono::duration<double, std::milli>(t_end - t_copied).count();
+        ctx->upload_device_build_ms = device_build ? std::chrono::duration<double, std::milli>(t_end - t_copied).count() : 0.0;
         return RT_OK;
     });
 }
@@ -737,7 +769,11 @@ int rt_debug_wave_fill(const rt_ctx *ctx, uint64_t out[6])
     return RT_OK;
 }
 
-float rt_debug_round_plane(float v, uint32_t payload, int down) { return with_low_byte(v, payload & 0xFFu, down != 0); }
+float rt_debug_round_plane(float v, uint32_t payload, int down)
+{
+    float out;
+    return pack_plane(v, payload & 0xFFu, down != 0, out) ? out : std::nanf("");
+}
 
 int rt_debug_block_counts(const rt_ctx *ctx, uint32_t cap, uint64_t *out)
 {
@@ -803,6 +839,7 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float *ac
     int rc = check_config(cfg);
     if (rc != RT_OK) return rc;
     if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
+    ctx->prog_active = false;             // shares d_accum / d_mean / d_rgb8 with a progressive render: that one ends here
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)cfg->nx * cfg->ny;
     if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;
@@ -886,6 +923,7 @@ int rt_render_reference_style(rt_ctx *ctx, const rt_camera *cam, const rt_config
     int rc = check_config(cfg);
     if (rc != RT_OK) return rc;
     if (ctx->n_sph == 0 && ctx->n_tri == 0) return RT_E_STATE;
+    ctx->prog_active = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)cfg->nx * cfg->ny;
     if ((rc = ensure(ctx, ctx->d_accum, ctx->accum_cap, npix * 3)) != RT_OK) return rc;
@@ -931,6 +969,7 @@ int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, c
         if (ctxs[g]->n_sph == 0 && ctxs[g]->n_tri == 0) return RT_E_STATE;
         devices[g] = ctxs[g]->device;
     }
+    for (uint32_t g = 0; g < n_ctx; ++g) ctxs[g]->prog_active = false;    // (uses every ctx's d_accum)
     rt_ctx *root = ctxs[0];
     const size_t npix = (size_t)cfg->nx * cfg->ny, nfl = npix * 3;
     const size_t gather_words = nfl + (raycount ? npix : 0);      // per peer: its sums, then its ray counts
@@ -962,7 +1001,8 @@ int rt_render_multi(rt_ctx *const *ctxs, uint32_t n_ctx, const rt_camera *cam, c
         RCCL_TRY(root, rccl().GroupStart());
         for (uint32_t g = 0; g < n_ctx; ++g) {
             rt_ctx *c = ctxs[g];
-            HIP_TRY(c, hipSetDevice(c->device));
+            const hipError_t he = hipSetDevice(c->device);
+            if (he != hipSuccess) { (void)rccl().GroupEnd(); c->last_hip = (int)he; return RT_E_HIP; }   // never leave the group open
             int r = rccl().Reduce(c->d_accum, c->d_accum, nfl, Rccl::Float32, Rccl::Sum, 0, root->rccl_comms[g], c->stream);
             if (r == 0 && raycount)
                 r = rccl().Reduce(c->d_raycount, c->d_raycount, npix, Rccl::Uint32, Rccl::Sum, 0, root->rccl_comms[g], c->stream);

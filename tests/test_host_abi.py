@@ -72,6 +72,49 @@ def test_packed_node_plane_rounding_only_moves_outward():
                 assert abs(key(r) - key(v)) < 512, (v, payload, down, r)
 
 
+def test_packed_node_plane_without_a_finite_neighbour_is_refused():
+    """planes at -inf (lower) / +inf (upper), NaN or in the last block of floats before +-FLT_MAX have no outward float carrying the
+    payload; the packer reports that (NaN here, RT_E_STATE from rt_upload_scene) instead of returning a plane whose
+    low byte is not the child ref."""
+    L = _lib.load()
+    fmax = float(np.finfo(np.float32).max)
+    for v, down in ((-np.inf, 1), (np.inf, 0), (np.nan, 1), (np.nan, 0), (-fmax, 1), (fmax, 0)):
+        for payload in (1, 77, 254):
+            assert np.isnan(L.rt_debug_round_plane(float(v), payload, down)), (v, payload, down)
+    # the inward side of +-FLT_MAX is fine
+    for payload in (0, 1, 254):
+        r = np.float32(L.rt_debug_round_plane(fmax, payload, 1))
+        assert np.isfinite(r) and r <= fmax and int(r.view(np.uint32)) & 0xFF == payload
+        r = np.float32(L.rt_debug_round_plane(-fmax, payload, 0))
+        assert np.isfinite(r) and r >= -fmax and int(r.view(np.uint32)) & 0xFF == payload
+
+
+def test_cu_mask_argument_check():
+    """rt_set_cu_mask's guard: a mask that leaves one of the 8 XCDs of an MI355X without
+    a CU (bit i lies on XCD i % 8) crashes the ROCm 7.2 runtime, so it is refused before any HIP call.  Pure host
+    arithmetic: no GPU, and no run reproduces the crash."""
+    L = _lib.load()
+
+    def check(words, cus=256):
+        m = (C.c_uint32 * len(words))(*words)
+        return L.rt_check_cu_mask(m, len(words), cus)
+
+    assert check([0xFFFFFFFF] * 8) == 256
+    assert check([0xFFFFFFFF]) == 32                         # 4 CUs per XCD: the "@1/8 GPU" mask
+    assert check([0xFF]) == 8                                # one CU per XCD
+    assert check([0x01010101]) == _lib.RT_E_ARG              # XCD 0 only
+    assert check([0x01010101] * 8) == _lib.RT_E_ARG          # all 32 CUs of XCD 0: "one XCD"
+    assert check([0x7F]) == _lib.RT_E_ARG                    # first 7 CUs: XCD 7 empty
+    assert check([0xFFFFFFFE & ~0x01010100]) == _lib.RT_E_ARG    # everything in the word but XCD 0
+    assert check([0, 0xFF]) == 8
+    assert check([0]) == _lib.RT_E_ARG
+    assert check([0] * 8 + [0xFFFFFFFF]) == _lib.RT_E_ARG    # only bits beyond the device's CUs
+    assert check([0xFF] + [0] * 7 + [0xFFFFFFFF]) == 8       # bits beyond the device's CUs are ignored
+    assert L.rt_check_cu_mask(None, 1, 256) == _lib.RT_E_ARG
+    assert check([0xFF] * 65) == _lib.RT_E_ARG
+    assert check([0x3], cus=2) == 2                          # a device with fewer CUs than XCD classes: no class rule
+
+
 def test_cameras_match_oracle_bitwise():
     assert np.array_equal(R.BasicCamera().as_array(), O.camera_basic().as_array())
     for nx, ny in ((1200, 675), (1920, 1080), (400, 225), (64, 36)):
