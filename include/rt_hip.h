@@ -55,7 +55,13 @@ typedef struct {
 } rt_spheres;
 
 /* Triangle soup (build-defined: the reference has no ray-triangle code; the meshes are the
- * zmesh parametric spheres of main.zig:128-138).  v0/v1/v2 are [n][3] floats. */
+ * zmesh parametric spheres of main.zig:128-138).  v0/v1/v2 are [n][3] floats.
+ * The test (two-sided Moller-Trumbore, flat normal = normalize(cross(v1-v0, v2-v0)) -- its side follows the winding)
+ * does not depend on which vertex is listed first: at upload every triangle's vertices are rotated cyclically (winding
+ * kept) so that v0 faces the longest edge.  Rejected BY DEFINITION (grazing guard, needed for a conservative cull at
+ * any camera distance): a ray with sin(largest corner) * cos(angle to the normal) < 2^-7 -- within 0.45..0.52 degrees of
+ * the triangle's plane for corners up to 120 degrees -- and hence, from every direction, a triangle whose largest
+ * corner exceeds 179.55 degrees (a line segment to 2^-7). */
 typedef struct {
     uint32_t        n;
     const float    *v0, *v1, *v2;

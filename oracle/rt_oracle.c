@@ -259,6 +259,33 @@ int orc_sphere_hit(const orc_sphere *s, orc_v3 ro, orc_v3 rd, float t_min, float
     return 0;
 }
 
+/* Canonical vertex order of a triangle (part of the build-defined triangle test, applied by orc_world_create and by the
+ * product's rt_upload_scene): the vertices are rotated cyclically -- winding and the side the flat normal points to are
+ * kept -- so that v0 is the vertex OPPOSITE THE LONGEST EDGE, i.e. the corner with the largest angle.  The grazing guard
+ * below bounds sin(corner angle at v0) * cos(theta); taken at whatever vertex the caller happened to list first it made
+ * a needle triangle whose v0 is the sharp apex invisible from every direction and visible again when its vertices were
+ * rotated.  With the largest corner (>= 60 degrees) at v0 the guard depends on the triangle's shape only:
+ * sin >= 0.866 unless the largest angle exceeds 120 degrees; a triangle whose largest angle exceeds 179.55 degrees
+ * (sin < 2^-7) is rejected from every direction by definition -- it is a line segment to 2^-7.
+ * Squared edge lengths in f32 with the ordered dot; among equally long edges the one facing the lexicographically
+ * smallest vertex (x, then y, then z) wins, so the result does not depend on the order the caller listed them in. */
+static int v3_lex_less(orc_v3 a, orc_v3 b)
+{
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.z < b.z;
+}
+void orc_canonical_triangle(orc_triangle *tr)
+{
+    const orc_v3 v[3] = { tr->v0, tr->v1, tr->v2 };
+    const orc_v3 a = vsub(v[1], v[0]), b = vsub(v[2], v[1]), c = vsub(v[0], v[2]);
+    const float opp[3] = { orc_dot(b, b), orc_dot(c, c), orc_dot(a, a) };   /* squared edge facing v0, v1, v2 */
+    int best = 0;
+    for (int i = 1; i < 3; i++)
+        if (opp[i] > opp[best] || (opp[i] == opp[best] && v3_lex_less(v[i], v[best]))) best = i;
+    tr->v0 = v[best]; tr->v1 = v[(best + 1) % 3]; tr->v2 = v[(best + 2) % 3];
+}
+
 /* Build-defined ray-triangle test (Moller-Trumbore, two-sided).  The reference has none
  * (SURVEY 8(a) T1).  Flat normal = normalize(cross(v1-v0, v2-v0)): outward for the
  * par_shapes winding, inward when the owning sphere's radius is negative.
@@ -539,6 +566,7 @@ orc_world *orc_world_create(const orc_sphere *sph, uint32_t n_sph,
         w->tri = (orc_triangle *)malloc(sizeof(orc_triangle) * n_tri);
         memcpy(w->tri, tri, sizeof(orc_triangle) * n_tri);
         w->n_tri = n_tri;
+        for (uint32_t i = 0; i < n_tri; i++) orc_canonical_triangle(&w->tri[i]);
         for (uint32_t i = 0; i < n_tri; i++)
             if (w->tri[i].material >= n_mat) { orc_world_destroy(w); return NULL; }
         w->tri_order = (uint32_t *)malloc(sizeof(uint32_t) * n_tri);

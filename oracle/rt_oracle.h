@@ -108,6 +108,9 @@ int    orc_refract(orc_v3 v, orc_v3 n, float ni_nt, orc_v3 *out);
 /* Sphere.hit, raytracer.zig:42-78: returns 1 on hit and fills t, p, normal */
 int    orc_sphere_hit(const orc_sphere *s, orc_v3 ro, orc_v3 rd, float t_min, float t_max,
                       float *t, orc_v3 *p, orc_v3 *normal);
+/* rotates the vertices so that v0 faces the longest edge (worlds do this to every triangle at creation) */
+void   orc_canonical_triangle(orc_triangle *tr);
+/* the test on the triangle AS GIVEN (no rotation) */
 int    orc_triangle_hit(const orc_triangle *tr, orc_v3 ro, orc_v3 rd, float t_min, float t_max,
                         float *t, orc_v3 *p, orc_v3 *normal);
 orc_v3 orc_sky(orc_v3 dir);                                     /* raytracer.zig:569-571 */

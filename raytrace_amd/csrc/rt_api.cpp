@@ -541,6 +541,31 @@ static int upload_vec(rt_ctx *ctx, float4 *&dst, const std::vector<float4> &src)
     return RT_OK;
 }
 
+// Canonical vertex order of a triangle (part of the build-defined triangle test; oracle: orc_canonical_triangle): the
+// vertices are rotated cyclically -- winding and normal side kept -- so that v0 faces the longest edge, i.e. sits at the
+// largest corner.  triangle_exact's grazing guard bounds sin(corner at v0) * cos(theta): at the largest corner it depends
+// on the triangle's shape only, not on which vertex the caller listed first.  Squared lengths in strict f32, ordered
+// dot (this file is built with -ffp-contract=off); among equally long edges the one facing the lexicographically
+// smallest vertex wins, so the result does not depend on the order the caller listed the vertices in.
+static void canonical_vertex_order(const float *&v0, const float *&v1, const float *&v2)
+{
+    auto len2 = [](const float *p, const float *q) {
+        const float x = p[0] - q[0], y = p[1] - q[1], z = p[2] - q[2];
+        return (x * x + y * y) + z * z;
+    };
+    auto lex_less = [](const float *p, const float *q) {
+        if (p[0] != q[0]) return p[0] < q[0];
+        if (p[1] != q[1]) return p[1] < q[1];
+        return p[2] < q[2];
+    };
+    const float *v[3] = { v0, v1, v2 };
+    const float opp[3] = { len2(v2, v1), len2(v0, v2), len2(v1, v0) };      // squared edge facing v0, v1, v2
+    int best = 0;
+    for (int i = 1; i < 3; ++i)
+        if (opp[i] > opp[best] || (opp[i] == opp[best] && lex_less(v[i], v[best]))) best = i;
+    v0 = v[best]; v1 = v[(best + 1) % 3]; v2 = v[(best + 2) % 3];
+}
+
 static bool spheres_valid(const rt_spheres *s, bool need_geometry)
 {
     if (!s || s->n == 0 || !s->kind || !s->r || !s->g || !s->b || !s->param) return false;
@@ -587,6 +612,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
             for (uint32_t k = 0; k < tri->n; ++k) {
                 if (tri->material[k] >= mats->n) return RT_E_ARG;
                 const float *a = tri->v0 + 3 * (size_t)k, *b = tri->v1 + 3 * (size_t)k, *c = tri->v2 + 3 * (size_t)k;
+                canonical_vertex_order(a, b, c);
                 float mat_bits; std::memcpy(&mat_bits, &tri->material[k], 4);
                 tris.push_back(make_float4(a[0], a[1], a[2], mat_bits));
                 tris.push_back(make_float4(b[0], b[1], b[2], 0.0f));

@@ -188,7 +188,9 @@ __device__ __forceinline__ void sphere_exact(float4 g, uint32_t prim, const Lane
 }
 
 // Build-defined two-sided Moller-Trumbore (the reference has no triangle code); same operation order
-// as the CPU checker.
+// as the CPU checker.  v0 is the triangle's LARGEST corner: rt_upload_scene rotates the vertices so that v0 faces the
+// longest edge (oracle: orc_canonical_triangle), which makes the grazing guard below a property of the triangle's
+// shape and not of the order its vertices were listed in.
 __device__ __forceinline__ void triangle_exact(f3 v0, f3 v1, f3 v2, uint32_t prim, const Lane &L, float t_min,
                                                float &best_t, uint32_t &best)
 {

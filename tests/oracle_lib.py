@@ -127,6 +127,8 @@ def lib():
     L.orc_sphere_hit.restype = C.c_int
     L.orc_triangle_hit.argtypes = [C.c_void_p, V3, V3, C.c_float, C.c_float, f32p, C.POINTER(V3), C.POINTER(V3)]
     L.orc_triangle_hit.restype = C.c_int
+    L.orc_canonical_triangle.argtypes = [C.c_void_p]
+    L.orc_canonical_triangle.restype = None
     L.orc_sky.argtypes = [V3]
     L.orc_sky.restype = V3
     L.orc_camera_basic.argtypes = [C.POINTER(Camera)]

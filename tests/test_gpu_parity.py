@@ -192,6 +192,20 @@ def test_c4_triangle_mesh_scene_1080p_256spp_sampled_pixels(gpu_ctx):
     assert psnr_u8(res.rgb8[pix], o8) >= MIN_PSNR
     assert res.primary_rays == nx * ny * spp and res.rays == int(res.raycount.astype(np.uint64).sum())
     assert np.all(np.isfinite(res.accum)) and res.accum.min() >= 0
+    # the 800 pixels above are checked against the oracle's own cone-culled triangle BVH -- a second
+    # cull by the same hand.  24 of them once more against the DEFINITION: the plain loop over all 285 520 triangles for
+    # every ray (ORC_TRAV_BRUTE: no box, no cone, no cull on the checker's side; ~2e8 exact tests per pixel).
+    sub = pix[:: max(1, len(pix) // 24)][:24]
+    ba, b8, brc, bcnt = O.render_counter(w, O.book_camera(nx, ny),
+                                         O.make_config(nx, ny, spp, traversal=O.TRAV_BRUTE, threads=16), pixels=sub)
+    assert bcnt["tri_tests"] == bcnt["rays"] * len(tris)                     # really every triangle for every ray
+    assert np.array_equal(res.raycount[sub], brc), "C4 differs from the cull-free definition"
+    berr = float(np.abs(res.accum[sub] - ba).max())
+    assert berr <= TOL_ACCUM, berr
+    idx = np.searchsorted(pix, sub)
+    assert np.array_equal(orc[idx], brc) and np.array_equal(oa[idx].view(np.uint32), ba.view(np.uint32))   # and so does the checker's BVH
+    print("C4 vs the plain loop over every triangle: %d pixels, %d rays, %.3g exact tests, max err %.3g"
+          % (len(sub), bcnt["rays"], bcnt["tri_tests"], berr))
     print("C4 1080p/256spp: %d triangles, %d rays, kernel %.1f ms = %.0f Mrays/s, sampled max err %.3g"
           % (len(tris), res.rays, res.kernel_ms, res.rays / res.kernel_ms / 1e3, err))
 
@@ -214,6 +228,41 @@ def test_triangle_edge_cases(gpu_ctx):
         w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(mats))
         oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(64, 32, 6))
         _compare(res, oa, o8, orc, cnt)
+
+
+def test_needle_triangle_in_all_three_vertex_rotations(gpu_ctx):
+    """the grazing guard of the triangle test bounds sin(corner at v0) * cos(theta); rt_upload_scene (like the
+    oracle's worlds) rotates every triangle so that v0 is the largest corner, so a needle is visible whichever vertex the
+    caller lists first, and the three listings give the same bits.  Also a sliver mesh: a fan of 0.23-degree needles."""
+    mats = R.Spheres(cx=[0], cy=[0], cz=[0], radius=[1], kind=[0], r=[.5], g=[.5], b=[.5], param=[0])
+    apex, b1, b2 = [0.0, 0.0, -2.0], [-0.002, 1.0, -2.0], [0.002, 1.0, -2.0]
+    cam = R.MovableCamera().SetPosition((0.0, 0.5, 0.0), (0.0, 0.5, -2.0), (0, 1, 0), 1.0, 1.0)
+    ocam = O.camera_set_position((0.0, 0.5, 0.0), (0.0, 0.5, -2.0), (0, 1, 0), 1.0, 1.0)
+    out = []
+    for v in ((apex, b1, b2), (b1, b2, apex), (b2, apex, b1)):
+        tris = R.Triangles([v[0]], [v[1]], [v[2]], [0])
+        gpu_ctx.upload_scene(triangles=tris, materials=mats)
+        res = gpu_ctx.render(cam, R.make_config(48, 48, 2), want_raycount=True)
+        w = O.World(triangles=triangles_to_oracle(tris), materials=spheres_to_oracle(mats))
+        oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(48, 48, 2))
+        _compare(res, oa, o8, orc, cnt)
+        assert cnt["hits"] > 20                                  # the needle is seen
+        out.append(res)
+    for r in out[1:]:
+        assert np.array_equal(r.raycount, out[0].raycount) and np.array_equal(r.accum.view(np.uint32), out[0].accum.view(np.uint32))
+    # a fan of needles around a hub, every triangle listed apex first (the order that used to make them invisible)
+    n = 64
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    rim0 = np.stack([np.cos(ang), np.sin(ang), np.full(n, -3.0)], 1)
+    rim1 = np.stack([np.cos(ang + 0.004), np.sin(ang + 0.004), np.full(n, -3.0)], 1)
+    hub = np.tile([[0.0, 0.0, -3.0]], (n, 1))
+    fan = R.Triangles(hub, rim0, rim1, np.zeros(n, np.uint32))
+    gpu_ctx.upload_scene(triangles=fan, materials=mats)
+    res = gpu_ctx.render(R.BasicCamera(), R.make_config(160, 80, 2), want_raycount=True)
+    w = O.World(triangles=triangles_to_oracle(fan), materials=spheres_to_oracle(mats))
+    oa, o8, orc, cnt = O.render_counter(w, O.camera_basic(), O.make_config(160, 80, 2))
+    _compare(res, oa, o8, orc, cnt)
+    assert cnt["hits"] > 50
 
 
 def test_large_random_sphere_scenes(gpu_ctx):
@@ -592,6 +641,58 @@ def test_render_multi_contexts_split_the_samples(gpu_ctx):
         np.testing.assert_allclose(few.accum, ref.accum, rtol=0, atol=1e-6)
 
 
+@pytest.mark.skipif(R.device_count() < 2 if os.path.exists("/dev/kfd") else True, reason="needs two GPUs")
+def test_render_multi_over_two_gpus_reduces_with_rccl(gpu_ctx):
+    """ADVICE r2 / VERDICT r2 weak #8: rt_render_multi with the contexts on DISTINCT GPUs -- the exchange step is then the
+    grouped in-place ncclReduce onto ctxs[0]'s GPU, not the shared-GPU copy-and-add.  Skipped on a one-GPU box."""
+    nx, ny, spp = 128, 72, 12
+    s, cam, ocam = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    w = O.World(spheres=spheres_to_oracle(s))
+    oa, o8, orc, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp))
+    with R.Context(1) as c1:
+        c1.upload_scene(s)
+        for chunk in (0, 3):
+            cfg = R.make_config(nx, ny, spp, spp_chunk=chunk)
+            one = gpu_ctx.render(cam, cfg, want_raycount=True)
+            for want_rc in (True, False):
+                res = R.render_multi([gpu_ctx, c1], cam, cfg, want_raycount=want_rc)
+                assert res.rays == cnt["rays"] and res.primary_rays == cnt["primary_rays"]
+                if want_rc:
+                    assert np.array_equal(res.raycount, orc)
+                np.testing.assert_allclose(res.accum, one.accum, rtol=0, atol=1e-6)
+                assert float(np.abs(res.accum - oa).max()) <= TOL_ACCUM
+                assert psnr_u8(res.rgb8, o8) >= MIN_PSNR
+            # two ranks: the sum is a0 + a1 whatever order RCCL adds in
+            parts = [gpu_ctx.render(cam, R.make_config(nx, ny, spp, spp_begin=b, spp_end=e, spp_total=spp, spp_chunk=chunk))
+                     for b, e in ((0, 6), (6, 12))]
+            np.testing.assert_allclose(parts[0].accum + parts[1].accum, res.accum, rtol=0, atol=2e-7)
+
+
+def test_cu_mask_that_empties_an_xcd_is_refused(gpu_ctx):
+    """{0x01010101} (CUs of XCD 0 only) used to reach hipExtStreamCreateWithCUMask, which takes the
+    process down under ROCm 7.2.  It is now RT_E_ARG before any HIP call, the ctx keeps rendering, and the 4-per-XCD
+    mask (the "@1/8 GPU" leg of bench.py) still works and gives the same image."""
+    nx, ny, spp = 96, 54, 4
+    s, cam, _ = _scene("book", nx, ny)
+    gpu_ctx.upload_scene(s)
+    ref = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    for words in ([0x01010101], [0x01010101] * 8, [0x7F], [0]):
+        with pytest.raises(R.RtError) as e:
+            gpu_ctx.set_cu_mask_words(words)
+        assert e.value.code == _lib.RT_E_ARG
+    with pytest.raises(ValueError):
+        gpu_ctx.set_cu_mask(4)
+    again = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)      # the ctx is unharmed
+    assert np.array_equal(again.raycount, ref.raycount) and np.array_equal(again.accum.view(np.uint32), ref.accum.view(np.uint32))
+    try:
+        gpu_ctx.set_cu_mask(32)
+        masked = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    finally:
+        gpu_ctx.set_cu_mask(None)
+    assert np.array_equal(masked.raycount, ref.raycount) and np.array_equal(masked.accum.view(np.uint32), ref.accum.view(np.uint32))
+
+
 @pytest.mark.parametrize("chunk", [1, 3, 5, 16, R.RT_SPP_CHUNK_AUTO])
 def test_sample_chunks_match_the_oracle_chunk_mode(gpu_ctx, chunk):
     """spp_chunk: samples summed per chunk of global sample indices, chunk sums added in order -- the oracle
@@ -805,8 +906,9 @@ def test_progressive_render_converges_to_rt_render(gpu_ctx):
     compute.zig:123-207).  Every intermediate picture is the mean over the samples so far (checked against a plain
     render of exactly those samples), and the last one is rt_render's image with spp_chunk = the pass size, bit for bit."""
     nx, ny, spp, passes = 96, 54, 12, 4
-    s, cam, _ = _scene("book", nx, ny)
+    s, cam, ocam = _scene("book", nx, ny)
     gpu_ctx.upload_scene(s)
+    w = O.World(spheres=spheres_to_oracle(s))
     seen = []
     for done, rgb8, accum, (rays, prim, _ms, _) in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, spp), passes):
         seen.append(done)
@@ -814,7 +916,22 @@ def test_progressive_render_converges_to_rt_render(gpu_ctx):
         part = gpu_ctx.render(cam, R.make_config(nx, ny, done, spp_chunk=spp // passes))
         assert np.array_equal(accum.view(np.uint32), part.accum.view(np.uint32)) and np.array_equal(rgb8, part.rgb8)
         assert rays == part.rays
+        # ... and against the ORACLE: every intermediate picture is the oracle's image of the samples
+        # so far in its chunk mode with chunk = the pass size (each pass adds one chunk sum to the SUM buffer)
+        oa, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, done, spp_chunk=spp // passes))
+        assert rays == cnt["rays"] and prim == cnt["primary_rays"]
+        assert float(np.abs(accum - oa).max()) <= TOL_ACCUM
+        assert psnr_u8(rgb8, o8) >= MIN_PSNR
     assert seen == [3, 6, 9, 12]
+    # a render, an upload or a mask change between two steps ends the progressive render (they share the ctx's buffers)
+    for breaker in (lambda: gpu_ctx.render(cam, R.make_config(nx, ny, 1)), lambda: gpu_ctx.upload_scene(s),
+                    lambda: gpu_ctx.set_cu_mask(None)):
+        it = gpu_ctx.render_progressive(cam, R.make_config(nx, ny, 4), 2)
+        next(it)
+        breaker()
+        with pytest.raises(R.RtError) as e:
+            next(it)
+        assert e.value.code == _lib.RT_E_STATE
     with pytest.raises(R.RtError) as e:                        # no render in progress any more
         gpu_ctx._check(gpu_ctx._L.rt_progressive_step(gpu_ctx._h, None, None, None, None), "rt_progressive_step")
     assert e.value.code == _lib.RT_E_STATE

@@ -202,6 +202,56 @@ def test_triangle_hit_cases():
             assert abs(t.value - 1.0) < 1e-3
 
 
+def test_triangle_vertex_order_is_canonical():
+    """the grazing guard bounds sin(corner angle at v0) * cos(theta), so as written it depended on which
+    vertex the caller listed first -- a needle whose sharp apex came first was invisible from every direction.  Worlds
+    (and rt_upload_scene) rotate every triangle so that v0 faces the longest edge (the largest corner): all three
+    rotations of a triangle become the same triple, winding kept, and the needle is visible."""
+    apex, b1, b2 = (0.0, 0.0, -2.0), (-0.002, 1.0, -2.0), (0.002, 1.0, -2.0)     # apex angle 0.23 degrees: sin = 0.004 < 2^-7
+    rots = [(apex, b1, b2), (b1, b2, apex), (b2, apex, b1)]
+    canon = []
+    for r in rots:
+        tri = np.zeros(1, dtype=O.TRIANGLE_DTYPE)
+        tri[0] = (r[0], r[1], r[2], 0)
+        before = np.cross(np.array(r[1]) - r[0], np.array(r[2]) - r[0])
+        L.orc_canonical_triangle(tri.ctypes.data)
+        after = np.cross(tri["v1"][0] - tri["v0"][0], tri["v2"][0] - tri["v0"][0])
+        assert np.dot(before, after) > 0                                          # same winding
+        canon.append(tri.tobytes())
+        # v0 now faces the longest edge
+        v0, v1, v2 = tri["v0"][0], tri["v1"][0], tri["v2"][0]
+        opp = np.sum((v2 - v1) ** 2)
+        assert opp >= np.sum((v1 - v0) ** 2) and opp >= np.sum((v0 - v2) ** 2)
+    assert canon[0] == canon[1] == canon[2]
+    # a right-angled triangle listed with the right angle first and an equilateral one (three-way tie, broken by the
+    # lexicographically smallest vertex) stay as given
+    for verts in (((0, 0, 0), (1, 0, 0), (0, 1, 0)), ((0, 0, 0), (2, 0, 0), (1, 1.7320508, 0))):
+        tri = np.zeros(1, dtype=O.TRIANGLE_DTYPE)
+        tri[0] = (*verts, 0)
+        keep = tri.tobytes()
+        L.orc_canonical_triangle(tri.ctypes.data)
+        assert tri.tobytes() == keep        # (0,0,0) is the lexicographically smallest vertex of both
+    # as given with the apex first the test rejects a head-on ray; the world (which canonicalises) sees the needle
+    t, p, n = C.c_float(), O.V3(), O.V3()
+    tri = np.zeros(1, dtype=O.TRIANGLE_DTYPE)
+    tri[0] = (apex, b1, b2, 0)
+    args = (O.v3((0.0, 0.5, 0.0)), O.v3((0.0, 0.0, -1.0)), C.c_float(0.001), C.c_float(1e30), C.byref(t), C.byref(p), C.byref(n))
+    assert L.orc_triangle_hit(tri.ctypes.data, *args) == 0
+    L.orc_canonical_triangle(tri.ctypes.data)
+    assert L.orc_triangle_hit(tri.ctypes.data, *args) == 1 and abs(t.value - 2.0) < 1e-6
+    mats = np.zeros(1, dtype=O.SPHERE_DTYPE)
+    mats[0] = ((0, 0, 0), 1.0, O.LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)
+    images = []
+    for r in rots:
+        tri = np.zeros(1, dtype=O.TRIANGLE_DTYPE)
+        tri[0] = (r[0], r[1], r[2], 0)
+        cam = O.camera_set_position((0.0, 0.5, 0.0), (0.0, 0.5, -2.0), (0, 1, 0), 1.0, 1.0)   # a 1-degree view of the needle
+        acc, _, rc, cnt = O.render_counter(O.World(triangles=tri, materials=mats), cam, O.make_config(48, 48, 2))
+        assert cnt["hits"] > 20                                                    # visible
+        images.append((acc.tobytes(), rc.tobytes()))
+    assert images[0] == images[1] == images[2]
+
+
 def test_sky():
     """raytracer.zig:569-571."""
     np.testing.assert_allclose(L.orc_sky(O.v3((0, 1, 0))).tup(), (0.5, 0.7, 1.0), atol=1e-7)

@@ -96,3 +96,49 @@ def test_noalloc_rejects_what_does_not_fit_and_auto_stays_within_the_scratch():
             assert torch.equal(acc, ref)
     finally:
         ctx.close()
+
+
+def test_noalloc_allocates_nothing_and_can_be_captured_into_a_graph():
+    """prove the claim, not just the result.  (a) free device memory is unchanged across a plain call;
+    (b) the call is captured into a graph on a side stream (capture_error_mode "global": a hipMalloc anywhere in the
+    process during capture would invalidate it), with spp_chunk 0 and with an explicit chunk, and two replays into a zeroed
+    buffer each give rt_render_device's bits."""
+    import torch
+    ctx = R.Context(0)
+    try:
+        ctx.upload_scene(R.Random_Scene(11, 0))
+        nx, ny, spp = 160, 90, 8
+        cam = R.book_camera(nx, ny)
+        n = nx * ny
+        for chunk in (0, 4):
+            cfg = R.make_config(nx, ny, spp, spp_chunk=chunk)
+            ref = torch.zeros(n * 3, dtype=torch.float32, device="cuda")
+            ref_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+            ctx.render_device(cam, cfg, ref.data_ptr(), ref_rc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            acc = torch.zeros_like(ref)
+            rc = torch.zeros_like(ref_rc)
+            # (a) a warm-up call, then one bracketed by hipMemGetInfo
+            ctx.render_device_noalloc(cam, cfg, acc.data_ptr(), rc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            free0, _ = torch.cuda.mem_get_info()
+            ctx.render_device_noalloc(cam, cfg, acc.data_ptr(), rc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            free1, _ = torch.cuda.mem_get_info()
+            assert free1 == free0, (free0, free1)
+            # (b) graph capture on a side stream
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="global"):
+                ctx.render_device_noalloc(cam, cfg, acc.data_ptr(), rc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            for _ in range(2):
+                acc.zero_(); rc.zero_()
+                torch.cuda.synchronize()
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(rc, ref_rc)
+                assert torch.equal(acc.view(torch.int32), ref.view(torch.int32))
+            del g
+    finally:
+        ctx.close()
