@@ -298,8 +298,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     if (fixed && p.n_chunks > 1 && (uint64_t)plane * p.n_chunks > fixed->partial_cap) return RT_E_CAP;
     uint32_t *const d_queue = fixed ? fixed->queue : ctx->d_queue;
     unsigned long long *const d_stats = fixed ? fixed->stats : ctx->d_stats;
-    HIP_TRY(ctx, hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
+    HIP_TRY(ctx, rt_launch_clear_pass(d_queue, d_stats, stream));
     const bool hist = (ctx->flags & RT_FLAG_DEPTH_HISTOGRAM) != 0;
     DeviceScene s;
     s.geom = ctx->d_geom; s.tri = ctx->d_tri; s.aux = ctx->d_aux; s.albedo = ctx->d_albedo; s.bvh = ctx->d_bvh;

@@ -88,6 +88,8 @@ const char *rt_trace_kernel_name(TraceKernel which);
 hipError_t rt_device_build_bvh(bool triangles, uint32_t n, const float4 *geom, const float4 *aux, const float4 *tri,
                                float4 *nodes, uint32_t depth_cap, int *depth, uint32_t *bad, hipStream_t stream);
 
+hipError_t rt_launch_clear_pass(uint32_t *queue, unsigned long long *stats, hipStream_t stream);
+
 hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,
                                    size_t plane_stride, hipStream_t stream);
 

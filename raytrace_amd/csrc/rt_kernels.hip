@@ -994,6 +994,15 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     }
 }
 
+// start of a pass: work-queue head and counters to zero.  A kernel rather than two hipMemsetAsync: under stream capture
+// (rt_render_device_noalloc) the 4-byte memset node did not run on replay with ROCm 7.2 -- the queue head kept the last
+// pass's value and every wave left at once -- and one launch is cheaper than two memsets anyway.
+__global__ __launch_bounds__(64) void rt_clear_pass_kernel(uint32_t *queue, unsigned long long *stats, uint32_t n_stats)
+{
+    if (threadIdx.x == 0) queue[0] = 0u;
+    for (uint32_t k = threadIdx.x; k < n_stats; k += 64u) stats[k] = 0ull;
+}
+
 // chunked mode: accum += (((p[0] + p[1]) + p[2]) + ...), the chunk partial sums added in sample order
 __global__ __launch_bounds__(256) void rt_reduce_chunks_kernel(float *accum, const float *partial, uint32_t n_values,
                                                                uint32_t n_chunks, size_t plane_stride)
@@ -1165,6 +1174,12 @@ hipError_t rt_launch_trace(TraceKernel which, const TraceParams &p, const Device
     RT_BVH(KIND_BVH_TRIANGLES)
 #undef RT_BVH
 #undef RT_ARGS
+}
+
+hipError_t rt_launch_clear_pass(uint32_t *queue, unsigned long long *stats, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_clear_pass_kernel, dim3(1), dim3(64), 0, stream, queue, stats, (uint32_t)RT_STATS_WORDS);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_reduce_chunks(float *accum_sum, const float *partial, uint32_t n_pixels, uint32_t n_chunks,

@@ -909,9 +909,11 @@ def test_progressive_render_converges_to_rt_render(gpu_ctx):
     s, cam, ocam = _scene("book", nx, ny)
     gpu_ctx.upload_scene(s)
     w = O.World(spheres=spheres_to_oracle(s))
-    seen = []
-    for done, rgb8, accum, (rays, prim, _ms, _) in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, spp), passes):
-        seen.append(done)
+    # (collected first: a plain render between two steps would end the progressive render, see below)
+    steps = [(done, rgb8.copy(), accum.copy(), rays, prim)
+             for done, rgb8, accum, (rays, prim, _ms, _) in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, spp), passes)]
+    seen = [st[0] for st in steps]
+    for done, rgb8, accum, rays, prim in steps:
         assert prim == nx * ny * done
         part = gpu_ctx.render(cam, R.make_config(nx, ny, done, spp_chunk=spp // passes))
         assert np.array_equal(accum.view(np.uint32), part.accum.view(np.uint32)) and np.array_equal(rgb8, part.rgb8)
