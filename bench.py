@@ -11,7 +11,9 @@ zero the accumulation buffer, trace every (pixel, sample) of this rank's sample 
 reduce; the analogue of the reference's thread join + average, raytracer.zig:605-617) and tonemap.
 Workload at N=1: BASELINE.json configs[2] -- book final scene, 1920x1080, 100 spp, depth cap 16.
 At N>1 every rank renders its own 100 global sample indices [100*rank, 100*(rank+1)) of a 100*N-spp
-image (weak scaling: per-GPU work fixed).
+image (weak scaling: per-GPU work fixed) -- the headline, metric-consistent with N=1 -- and, when no
+--workload is named, the same line carries a `c5_strong` block: BASELINE.json configs[4], 3840x2160 with
+1024 spp SPLIT over the ranks (the reference's thread fan-out, raytracer.zig:588-617), a few steps of its own.
 
 Prints ONE JSON line on rank 0.  The CPU baseline leg (rank 0, N=1 only) times the oracle's
 restatement of render_and_write on the host cores; it is the only use of oracle/ here.
@@ -118,11 +120,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default c3 (the headline); with --gpus N > 1 and no --workload the line also carries a "
+                         "c5_strong block (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-eighth", action="store_true", help="skip the 32-CU (1/8 GPU) leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    workload_given = args.workload is not None
+    if not workload_given:
+        args.workload = "c3"
 
     import numpy as np
     import torch
@@ -159,47 +166,41 @@ def main():
         ctx.upload_scene(triangles=tris, materials=spheres)
     else:
         ctx.upload_scene(spheres)
-    from raytrace_amd.distributed import HipRangeRenderer, render_sample_sharded
+    from raytrace_amd.distributed import HipRangeRenderer, timed_sharded_steps
     npix = nx * ny
     renderer = HipRangeRenderer(ctx, cam, nx, ny, max_depth=depth, seed=1)
     accum = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")
 
     strong = args.workload in STRONG
     spp_total = spp if strong else spp * world      # weak: every GPU adds its own `spp` samples to the image
-    kernel_ms = []
-    reduce_ms = []
-    rays_per_step = [0]
+    # a step: zero accum -> trace this rank's samples [rank*spp, (rank+1)*spp) -> RCCL reduce -> tonemap on rank 0;
+    # warmup untimed, then exactly --steps steps between fences (synchronize + barrier), MAX over ranks
+    timed = timed_sharded_steps(renderer, spp_total, dist, steps=args.steps, warmup=args.warmup, accum=accum)
+    kernel_ms, reduce_ms = [timed["kernel_ms"]], [timed["reduce_ms"]]
+    rays_per_step = [timed["rays_rank"]]
+    rays_all = timed["rays_per_step"]            # rays of ONE step over all ranks
+    dt = timed["seconds"]
 
-    def step(record):
-        # zero accum -> trace this rank's samples [rank*spp, (rank+1)*spp) -> RCCL reduce -> tonemap on rank 0
-        res = render_sample_sharded(renderer, spp_total, dist, accum)
-        if record:
-            kernel_ms.append(res.kernel_ms)
-            reduce_ms.append(res.reduce_ms)
-            rays_per_step[0] = res.rays
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-
-    rays_total = torch.tensor([float(rays_per_step[0])], dtype=torch.float64, device="cuda")
-    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    rays_all = float(rays_total.item())          # rays of ONE step over all ranks
-    dt = float(t_max.item())
+    # BASELINE configs[4] (C5: 3840x2160, 1024 spp SPLIT over the GPUs -- the reference's thread fan-out,
+    # raytracer.zig:588-617): measured beside the weak-scaling headline whenever the driver runs --gpus N > 1
+    # without naming a workload.  Its own short step count: one 4K step is ~620/N ms.
+    c5 = None
+    if world > 1 and not workload_given:
+        _, nx5, ny5, spp5, depth5, op5 = WORKLOADS["c5"]
+        r5 = HipRangeRenderer(ctx, R.book_camera(nx5, ny5), nx5, ny5, max_depth=depth5, seed=1)
+        del accum
+        t5 = timed_sharded_steps(r5, spp5, dist, steps=max(1, min(3, args.steps)), warmup=1)
+        with open(os.path.join(ROOT, "tests", "golden", op5)) as f:
+            fpr5 = json.load(f)["flops_per_ray"]
+        mr5 = t5["rays_per_step"] / (t5["ms_per_step"] * 1e-3) / 1e6
+        c5 = {"workload": WORKLOAD_DESC["c5"], "scaling": "strong", "nx": nx5, "ny": ny5, "spp_total": spp5,
+              "spp_per_gpu": spp5 / world, "steps": t5["steps"], "warmup": 1, "ms_per_step": t5["ms_per_step"],
+              "value": mr5, "unit": "Mrays/s", "rays_per_step": t5["rays_per_step"],
+              "kernel_ms_rank0": t5["kernel_ms"], "reduce_ms_rank0": t5["reduce_ms"],
+              "frac_of_n_x_157.3TF": mr5 * 1e6 * fpr5 / 1e12 / (PEAK_FP32_TFLOPS * world),
+              "algorithmic_flops_per_ray": fpr5, "backend": t5["backend"],
+              "rccl_ranks": t5["world"] if t5["backend"] == "nccl" else 0,
+              "parallelism": "spp-range x%d (shard_spp) + one reduce(SUM, dst 0) of 99.5 MB + tonemap on rank 0" % world}
 
     if rank == 0:
         value = rays_all * args.steps / dt / 1e6
@@ -209,11 +210,12 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         # HBM bytes per launch of the trace kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE,
         # WRITE_SIZE; tools/profile_bench.sh), committed under profiles/: counters cannot be read in-process.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_git = None, None, None
         pmc_path = os.path.join(ROOT, "profiles", "latest_%s_pmc.json" % args.workload)
         if world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                d = json.load(f).get("derived", {})
+                pj = json.load(f)
+            d, pmc_git = pj.get("derived", {}), pj.get("git", "unrecorded (profile older than round 3)")
             if "hbm_write_bytes" in d and "hbm_read_bytes_x2_correction" in d:
                 # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) counts half the bytes on gfx950 -> doubled; WRITE_SIZE as is
                 traffic = d["hbm_read_bytes_x2_correction"] + d["hbm_write_bytes"]
@@ -256,6 +258,9 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "executed": executed, "l1_gather": l1,
+                         # traffic / executed / l1_gather are read from the committed counter pass of the same command,
+                         # not collected by this process (counters need rocprofv3 around it)
+                         "counters_measured_in_run": False, "counters_profile_git": pmc_git,
                          "scope": "rank 0's GPU" if world > 1 else "the GPU",
                          "kernel": ctx.last_kernel_name(), "kernel_ms": k_ms,
                          "algorithmic_flops_per_ray": fpr, "rays_per_launch": rays_per_step[0],
@@ -283,6 +288,8 @@ def main():
                                               "frac": a8 / (PEAK_FP32_TFLOPS / 8), "kernel_ms": k8,
                                               "mrays_per_s": r8 / (k8 * 1e-3) / 1e6,
                                               "note": "same workload and kernel on a CU-masked stream: 32 CUs, 4 on each XCD"}
+        if c5 is not None:
+            out["c5_strong"] = c5
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_threads()
             out["cpu_baseline"] = cpu_baseline(args.workload, threads)

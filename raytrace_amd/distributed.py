@@ -110,6 +110,52 @@ def render_sample_sharded(renderer, spp_total, dist=None, accum=None):
     return ShardedResult(None, None, rays, ms, reduce_ms)
 
 
+def timed_sharded_steps(renderer, spp_total, dist=None, steps=3, warmup=1, accum=None):
+    """bench.py's timed region, for any workload: `warmup` untimed then exactly `steps` timed calls of
+    render_sample_sharded, bracketed by synchronize + barrier on both sides; the time is the MAX over ranks, the rays
+    the SUM over ranks.  Every rank returns the same dict:
+        ms_per_step, rays_per_step (all ranks), rays_rank (this rank), kernel_ms (this rank's mean), reduce_ms (this
+        rank's mean wall time of the exchange step), world, backend."""
+    import time
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    dev = renderer.device()
+    on_gpu = dev.type == "cuda"
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    if accum is None:
+        accum = torch.zeros(renderer.nx * renderer.ny * 3, dtype=torch.float32, device=dev)
+    kernel_ms, reduce_ms, rays = [], [], 0
+    for _ in range(warmup):
+        render_sample_sharded(renderer, spp_total, dist, accum)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = render_sample_sharded(renderer, spp_total, dist, accum)
+        kernel_ms.append(res.kernel_ms)
+        reduce_ms.append(res.reduce_ms)
+        rays = res.rays
+    fence()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([float(rays), 0.0], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    return {"ms_per_step": dt / max(1, steps) * 1e3, "rays_per_step": float(tot[0].item()), "rays_rank": rays,
+            "kernel_ms": float(np.mean(kernel_ms)) if kernel_ms else 0.0,
+            "reduce_ms": float(np.mean(reduce_ms)) if reduce_ms else 0.0,
+            "world": world, "backend": dist.get_backend() if dist is not None else "none", "steps": steps, "seconds": dt}
+
+
 def quantise(mean):
     """Host tonemap, trunc(255.99*sqrt(mean)) (raytracer.zig:527,545-549), for stand-in renderers."""
     return np.clip((np.float32(255.99) * np.sqrt(np.asarray(mean, dtype=np.float32))).astype(np.int32), 0, 255).astype(np.uint8)

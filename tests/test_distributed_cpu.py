@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from raytrace_amd.distributed import render_sample_sharded, shard_rows, shard_spp, quantise
+from raytrace_amd.distributed import render_sample_sharded, shard_rows, shard_spp, quantise, timed_sharded_steps
 
 NX, NY, SPP = 48, 27, 10
 
@@ -107,3 +107,49 @@ def test_sample_sharded_render_matches_single_process(world):
     assert rays == cnt["rays"]                                   # sample assignment is exact
     np.testing.assert_allclose(mean.reshape(-1, 3), ref_mean, rtol=0, atol=2e-6)   # float sums reorder across ranks
     assert (rgb8.reshape(-1, 3).astype(int) - ref_rgb8.astype(int)).__abs__().max() <= 1
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's timed region at world 2 (timed_sharded_steps is the function bench.py calls for the weak headline and
+    for the c5_strong block): the STRONG split -- SPP samples divided by shard_spp -- on a tiny image."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = timed_sharded_steps(OracleRangeRenderer(NX, NY), SPP, dist, steps=2, warmup=1)
+        q.put((rank, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timed_region_two_ranks_strong_split():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    w = O.World(spheres=O.random_scene(11, 0))
+    _, _, _, cnt = O.render_counter(w, O.book_camera(NX, NY), O.make_config(NX, NY, SPP))
+    a, b = got[0], got[1]
+    # every rank holds the same whole-job figures: rays summed over ranks == the single-process render, MAX time
+    assert a["rays_per_step"] == b["rays_per_step"] == float(cnt["rays"])
+    assert a["rays_rank"] + b["rays_rank"] == cnt["rays"] and a["rays_rank"] > 0 and b["rays_rank"] > 0
+    assert a["ms_per_step"] == b["ms_per_step"] > 0 and a["steps"] == 2 and a["world"] == 2 and a["backend"] == "gloo"
+
+
+def test_bench_line_carries_c5_strong_only_for_unnamed_multi_gpu_runs():
+    """bench.py's contract, checked on its text: the c5_strong block is built when world > 1 and no
+    --workload was named, from WORKLOADS['c5'] = BASELINE configs[4]."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    ast.parse(src)
+    assert "if world > 1 and not workload_given:" in src and 'out["c5_strong"] = c5' in src
+    assert '"c5": ("book", 3840, 2160, 1024, 16' in src and "timed_sharded_steps(r5, spp5, dist" in src

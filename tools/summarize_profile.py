@@ -55,8 +55,21 @@ if "SQ_INSTS_VALU" in agg and "GRBM_GUI_ACTIVE" in agg:
     # of them; 1.7 ns is the yardstick for this instruction mix.
     d["valu_ns_per_inst_per_simd"] = bench["roofline"]["kernel_ms"] * 1e6 * 1024 / agg["SQ_INSTS_VALU"]
     d["valu_issue_vs_measured_rate"] = 1.7 / d["valu_ns_per_inst_per_simd"]
-out = {"workload": bench["config"]["workload"], "dispatch": info, "counters_one_launch": dict(agg), "derived": d,
-       "bench": {k: bench[k] for k in ("value", "ms_per_step")}, "roofline": bench["roofline"]}
+# Only what THIS run's bench line measured itself goes into the summary: the line's traffic / executed / l1_gather blocks
+# are cross-references to an EARLIER committed counter pass (bench.py marks them "measured_in_run": false) and must not
+# be carried into a new profile.
+roof = {k: v for k, v in bench["roofline"].items() if k not in ("traffic", "traffic_source", "executed", "l1_gather",
+                                                                "counters_measured_in_run", "counters_profile_git")}
+try:
+    import subprocess
+    git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "raytrace_amd"], capture_output=True, text=True,
+                                timeout=10).stdout.strip())
+    git = git + ("+dirty" if dirty else "")
+except Exception:
+    git = "unknown"
+out = {"workload": bench["config"]["workload"], "git": git, "dispatch": info, "counters_one_launch": dict(agg), "derived": d,
+       "bench": {k: bench[k] for k in ("value", "ms_per_step")}, "roofline": roof}
 json.dump(out, open("profiles/%s_pmc.json" % name, "w"), indent=1)
 if len(sys.argv) > 3:
     shutil.copy("profiles/%s_pmc.json" % name, "profiles/latest_%s_pmc.json" % sys.argv[3])
