@@ -250,17 +250,6 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     p.queue_batch = p.n_chunks > 1 ? 128u : 64u;    // coarse items (whole pixels): reserve less, the tail is long enough
     if (tune.queue_batch) p.queue_batch = tune.queue_batch;
     p.n_items = (uint32_t)(pixel_items * p.n_chunks);
-    // queue regions: bands of whole tiles (all chunks of a tile in one region)
-#ifndef RT_QUEUE_REGIONS
-#define RT_QUEUE_REGIONS 1
-#endif
-    p.n_regions = triangles ? RT_QUEUE_REGIONS : 1u;
-    {
-        const uint64_t tile_items = 64ull * p.n_chunks, tiles = (uint64_t)p.tiles_x * tiles_y;
-        const uint64_t per = (tiles + p.n_regions - 1) / p.n_regions;
-        p.region_items = (uint32_t)(per * tile_items);
-        if (p.n_regions <= 1u) p.region_items = p.n_items;
-    }
     p.q3 = cfg->row_offset_q3 ? 1u : 0u;
     p.n_prim = n_prim;
     // leave the traversal loop to test/shade when fewer lanes than this still traverse (measured on MI355X: sphere
@@ -677,15 +666,14 @@ int rt_upload_scene(rt_ctx *ctx, const rt_spheres *sph, const rt_triangles *tri,
                 }
                 float *d = slot(it.wide);
                 for (int ax = 0; ax < 3; ++ax) {
-                    float *a = d + (RT_WIDE_NODE_BYTES == 128 ? 8 : 12) * ax;   // {hi0..hi3, lo0..lo3, hi0..hi3}; 128-byte nodes: {hi0..hi3, lo0..lo3}
+                    float *a = d + 12 * ax;                                  // {hi0..hi3, lo0..lo3, hi0..hi3}
                     for (int c = 0; c < 4; ++c) {
                         float l = inf, h = -inf;
                         if (c < nc) {
                             const uint32_t b = (packed_ref[c] >> (8 * ax)) & 0xFFu;
                             if (!pack_plane(lo[c][ax], b, true, l) || !pack_plane(hi[c][ax], b, false, h)) return RT_E_STATE;
                         }
-                        a[c] = h; a[4 + c] = l;
-                        if (RT_WIDE_NODE_BYTES != 128) a[8 + c] = h;
+                        a[c] = h; a[4 + c] = l; a[8 + c] = h;
                     }
                 }
             }

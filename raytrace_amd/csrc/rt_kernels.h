@@ -20,7 +20,6 @@ struct TraceParams {
     uint32_t n_prim;
     uint32_t spp_chunk, chunk0, n_chunks;   // n_chunks > 1: samples summed per chunk into partial planes
     uint32_t queue_batch;                   // work items a wave reserves per global atomic (>= 64)
-    uint32_t n_regions, region_items;       // BVH kernels: the item space in n_regions (1..8) contiguous regions of region_items items, one queue head each
     size_t   plane_stride;                  // floats between partial planes
     uint32_t force_global_scene;            // BVH kernels: 1 = never stage the scene in LDS (test/tuning knob)
     uint32_t flush_lanes;                   // BVH kernels: run the exact tests when this many lanes hold candidates
@@ -51,10 +50,7 @@ constexpr uint32_t RT_PACKED_LEAF_BIT = 0x800000u;
 // {hi0..hi3, lo0..lo3, hi0..hi3}: a lane reads 32 bytes at +16 (ray runs up the axis) or +0 (down) and gets
 // {near0..near3, far0..far3}.  Refs as in the packed node (24 bits in the low mantissa bytes of the child's planes;
 // inner = index of a wide node).  A missing child has lo = +inf, hi = -inf (never hit) and a zero ref.
-#ifndef RT_WIDE_NODE_BYTES_DEF
-#define RT_WIDE_NODE_BYTES_DEF 144
-#endif
-#define RT_WIDE_NODE_BYTES RT_WIDE_NODE_BYTES_DEF
+constexpr int RT_WIDE_NODE_BYTES = 144;
 constexpr int RT_WIDE_STACK = 34;        // 3 pushes per level, leaves included: trees of at most 11 wide levels (binary depth cap 22)
 
 struct DeviceScene {

@@ -366,7 +366,7 @@ struct Outputs {
     float              *partial;   // chunked mode: [n_chunks][P*3] partial sums, each cell written by one lane
     uint32_t           *raycount;
     uint32_t           *queue;
-    uint32_t           *wave_queue;   // LDS: this wave's reserved item range {next, end} (+ BVH kernels: {region, dry})
+    uint32_t           *wave_queue;   // LDS: this wave's reserved item range {next, end}
     unsigned long long  my_rays, my_primary;
 };
 
@@ -395,43 +395,18 @@ __device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bo
         // wave's leader lane); the lanes that need an item take consecutive ones from it (ballot + popcount
         // rank), and only when the range runs dry does the leader reserve the next P.queue_batch items with ONE
         // atomic on the global head.  (One atomic per item saturates a single counter at this kernel's rate.)
-        // The item space is cut into P.n_regions contiguous REGIONS (bands of 8x8 tiles), each with its own head
-        // (O.queue[8 r]).  A wave starts on the region of the XCD it runs on and moves to the next region that still
-        // has items when its own runs dry, so the waves that share an L2 work on one part of the image -- and of the
-        // scene -- for as long as that part lasts.  n_regions = 1 is the single queue.  Which wave renders which item
-        // never enters the arithmetic.
         const unsigned long long m = wave_ballot(1);
         const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-        uint32_t q_next = 0, q_avail = 0, q_new = 0, q_new_n = 0, q_dry = 0;
+        uint32_t q_next = 0, q_avail = 0, q_new = 0;
         if (lane == leader) {
-            uint32_t *wq = O.wave_queue;              // {next, end, region, all regions dry}
+            uint32_t *wq = O.wave_queue;
             q_next = wq[0];
             q_avail = wq[1] - q_next;
             if (cnt > q_avail) {
-                uint32_t r = wq[2], end = 0;
-                q_dry = wq[3];
-                if (!q_dry) {
-                    q_dry = 1u;
-                    for (uint32_t tries = 0; tries < P.n_regions; ++tries) {
-                        const uint32_t rb = r * P.region_items;
-                        const uint32_t left = rb < P.n_items ? P.n_items - rb : 0u;
-                        const uint32_t rlen = left < P.region_items ? left : P.region_items;
-                        const uint32_t q = atomicAdd(&O.queue[8u * r], P.queue_batch);
-                        if (q < rlen) {
-                            q_new = rb + q;
-                            q_new_n = rlen - q < P.queue_batch ? rlen - q : P.queue_batch;
-                            end = q_new + q_new_n;
-                            q_dry = 0u;
-                            break;
-                        }
-                        r = r + 1u == P.n_regions ? 0u : r + 1u;
-                    }
-                    wq[2] = r; wq[3] = q_dry;
-                }
-                const uint32_t want = cnt - q_avail;
-                wq[0] = q_new + (want < q_new_n ? want : q_new_n);
-                wq[1] = end;
+                q_new = atomicAdd(O.queue, P.queue_batch);
+                wq[0] = q_new + (cnt - q_avail);
+                wq[1] = q_new + P.queue_batch;
             } else {
                 wq[0] = q_next + cnt;
             }
@@ -439,13 +414,10 @@ __device__ __forceinline__ bool advance_direct(const TraceParams &P, Lane &L, bo
         q_next = __builtin_amdgcn_readfirstlane(q_next);   // leader = first active lane
         q_avail = __builtin_amdgcn_readfirstlane(q_avail);
         q_new = __builtin_amdgcn_readfirstlane(q_new);
-        q_new_n = __builtin_amdgcn_readfirstlane(q_new_n);
-        q_dry = __builtin_amdgcn_readfirstlane(q_dry);
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const bool got = rank < q_avail + q_new_n;
         const uint32_t item = rank < q_avail ? q_next + rank : q_new + (rank - q_avail);
-        if (!got) {
-            if (q_dry) alive = false;                 // every region is drained; otherwise the lane asks again in its next pass
+        if (item >= P.n_items) {
+            alive = false;
         } else {
             // item -> (tile, chunk, pixel): 8x8 tiles, row-major inside a tile, so a wave starts on one
             // coherent tile; the chunks of a tile are consecutive items
@@ -738,11 +710,9 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     __shared__ unsigned long long s_wbest[SHARED_Q ? NT : 1];      // per lane: bits(t) << 32 | triangle: min = closest, ties to the lower index
     extern __shared__ float4 s_scene[];               // LDSN: [n_nodes * 5] nodes, then [n_prim] sphere records
     const float4 *s_geom = s_scene + (LDSN ? n_nodes * LDS_NODE_STRIDE : 0u);
-    __shared__ uint32_t s_wq[4 * (NT / 64)];
+    __shared__ uint32_t s_wq[2 * (NT / 64)];
     if (HIST && threadIdx.x < RT_HIST_WORDS + 2 * RT_PROF_BLOCKS) s_hist[threadIdx.x] = 0;
-    // every wave starts on the queue region of its XCD (HW_REG_XCC_ID, bits 3:0: the waves that share an L2)
-    if (threadIdx.x < 4 * (NT / 64))
-        s_wq[threadIdx.x] = (threadIdx.x & 3u) == 2u ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) % P.n_regions : 0u;
+    if (threadIdx.x < 2 * (NT / 64)) s_wq[threadIdx.x] = 0;
     if (LDSN) {
         // the device nodes are already in traversal format (80 bytes, child refs = byte offsets): straight copy.
         // The 80-byte stride also spreads 16 lanes' reads of random nodes over all bank quads.
@@ -760,7 +730,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     L.pix = NOPIX; L.i = 0; L.j = 0; L.sample = 0; L.send = 0; L.part = 0; L.depth = 0; L.nrays = 0;
     L.nx_pix = NOPIX; L.nx_i = 0; L.nx_j = 0; L.nx_part = 0; L.dry = false;
     bool alive = true, has_ray = false;
-    Outputs O{ accum, partial, raycount, queue, s_wq + 4 * (threadIdx.x >> 6), 0ull, 0ull };
+    Outputs O{ accum, partial, raycount, queue, s_wq + 2 * (threadIdx.x >> 6), 0ull, 0ull };
 
     // traversal state of the lane's current ray
     uint32_t node = DONE, sp = 0, ncand = 0, best = NOHIT;
@@ -855,10 +825,9 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     a = dot(L.d, L.d);
                     ray_splat(RS, L.o, L.d, a, KIND == KIND_BVH_SPHERES ? RT_CONE_SPHERES : RT_CONE_TRIANGLES);
                     if (WIDE) {                       // wide axis record {hi x4, lo x4, hi x4}: near quad at +16 (up) or +0 (down), far quad behind it
-                        constexpr uint32_t AXIS = RT_WIDE_NODE_BYTES == 128 ? 32u : 48u;
                         RS.ox = ((__float_as_uint(L.d.x) >> 31) ^ 1u) << 4;
-                        RS.oy = AXIS + (((__float_as_uint(L.d.y) >> 31) ^ 1u) << 4);
-                        RS.oz = 2u * AXIS + (((__float_as_uint(L.d.z) >> 31) ^ 1u) << 4);
+                        RS.oy = 48u + (((__float_as_uint(L.d.y) >> 31) ^ 1u) << 4);
+                        RS.oz = 96u + (((__float_as_uint(L.d.z) >> 31) ^ 1u) << 4);
                     }
                     node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                     if (SHARED_Q) s_wbest[tid] = NO_HIT_KEY;
@@ -890,18 +859,10 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                     if (HIST) c_lsteps += 1;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const char *const nbase = (const char *)bvh;
-#if RT_WIDE_NODE_BYTES == 128
-                    // one node = one 128-byte line; the far quad of an axis is the other half of its 32-byte record
-                    const uint32_t noff = node << 7;
-                    const v4f xn = *(const v4f *)(nbase + (noff + RS.ox)), xf = *(const v4f *)(nbase + ((noff + RS.ox) ^ 16u));
-                    const v4f yn = *(const v4f *)(nbase + (noff + RS.oy)), yf = *(const v4f *)(nbase + ((noff + RS.oy) ^ 16u));
-                    const v4f zn = *(const v4f *)(nbase + (noff + RS.oz)), zf = *(const v4f *)(nbase + ((noff + RS.oz) ^ 16u));
-#else
                     const uint32_t noff = __umul24(node, (uint32_t)RT_WIDE_NODE_BYTES);
                     const v4f xn = *(const v4f *)(nbase + (noff + RS.ox)), xf = *(const v4f *)(nbase + (noff + RS.ox + 16u));
                     const v4f yn = *(const v4f *)(nbase + (noff + RS.oy)), yf = *(const v4f *)(nbase + (noff + RS.oy + 16u));
                     const v4f zn = *(const v4f *)(nbase + (noff + RS.oz)), zf = *(const v4f *)(nbase + (noff + RS.oz + 16u));
-#endif
                     uint32_t ref[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1038,7 +999,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 // pass's value and every wave left at once -- and one launch is cheaper than two memsets anyway.
 __global__ __launch_bounds__(64) void rt_clear_pass_kernel(uint32_t *queue, unsigned long long *stats, uint32_t n_stats)
 {
-    queue[threadIdx.x] = 0u;                          // the heads of up to 8 queue regions, 32 bytes apart (256 bytes)
+    if (threadIdx.x == 0) queue[0] = 0u;
     for (uint32_t k = threadIdx.x; k < n_stats; k += 64u) stats[k] = 0ull;
 }
 
