@@ -15,7 +15,8 @@ if "3" in only or not only:
     ctx.upload_scene(book)
     for _ in range(3):
         res = ctx.render(cam, R.make_config(1920, 1080, 100, spp_chunk=R.RT_SPP_CHUNK_AUTO))
-    print("C3 %8.2f ms %8.0f Mrays/s" % (res.kernel_ms, res.rays / res.kernel_ms / 1e3), end="   ")
+    r3 = ctx.render(cam, R.make_config(1920, 1080, 4), want_raycount=True)
+    print("C3 %8.2f ms %8.0f Mrays/s [crc rc %08x acc %08x]" % (res.kernel_ms, res.rays / res.kernel_ms / 1e3, zlib.crc32(r3.raycount.tobytes()), zlib.crc32(np.ascontiguousarray(r3.accum).tobytes())), end="   ")
 if "2" in only or not only:
     ctx.upload_scene(R.Two_Sphere_Scene())
     for _ in range(3):
