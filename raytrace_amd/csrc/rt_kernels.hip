@@ -744,9 +744,6 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     RS.nx = RS.ny = RS.nz = RS.fx = RS.fy = RS.fz = RS.ex = RS.ey = RS.ez = (v2f){ 1.0f, 0.0f };
     RS.ox = 8u; RS.oy = NODE_AXIS_BYTES + 8u; RS.oz = 2u * NODE_AXIS_BYTES + 8u;
     RS.perp = false;
-#ifdef RT_EXP_DEFER
-    bool deferred = false;            // this lane's hit waited in the last shading pass
-#endif
     bool wave_perp = false;           // wave-uniform: some lane's current ray has an axis inside its cone
     float t_min_v = P.t_min;
     asm volatile("" : "+v"(t_min_v));
@@ -800,37 +797,12 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 
     for (;;) {
         // ---- lanes whose traversal is complete: exact tests, shade, next ray --------------------------
-#ifdef RT_EXP_DEFER
-        // Experiment: a lane whose ray hit metal or glass waits ONE shading pass while fewer than
-        // RT_EXP_DEFER lanes of the wave hold such a hit, so that those two blocks run less often and fuller.  Nothing
-        // but the pass in which a hit is shaded changes.  Every turn of the outer loop still shades a lane or steps one:
-        // with no lane traversing nothing new is deferred and the waiting lanes are shaded.
-        const bool some_traverse = wave_ballot(node != DONE) != 0ull;
-        if (wave_ballot(node == DONE && (has_ray || alive) && !deferred) != 0ull || !some_traverse) {
-#else
         if (wave_ballot(node == DONE && (has_ray || alive)) != 0ull) {
-#endif
             // drain the queues of the finished lanes; lanes still traversing join each batch (their best_t tightens)
             if constexpr (SHARED_Q) { while (wcount != 0u) test_batch(); }
             else { while (wave_ballot(node == DONE && ncand != 0u) != 0ull) test_one(); }
             if (HIST) c_wshade += 1;
-#ifdef RT_EXP_DEFER
-            bool defer = false;
-            {
-                const bool special_hit = node == DONE && has_ray && best != NOHIT && L.depth <= P.max_depth;
-                uint32_t kind = K_LAMBERTIAN;
-                if (special_hit) {
-                    const uint32_t mat = KIND == KIND_BVH_TRIANGLES ? __float_as_uint(tri[3u * best].w) : best;
-                    kind = __float_as_uint(aux[mat].y);
-                }
-                const uint32_t n_met = (uint32_t)__popcll(wave_ballot(kind == K_METAL)), n_die = (uint32_t)__popcll(wave_ballot(kind == K_DIELECTRIC));
-                defer = some_traverse && !deferred && ((kind == K_METAL && n_met < RT_EXP_DEFER) || (kind == K_DIELECTRIC && n_die < RT_EXP_DEFER));
-                deferred = defer;
-            }
-            if (node == DONE && !defer) {
-#else
             if (node == DONE) {
-#endif
                 if (HIST && has_ray) c_lshade += 1;
                 shade_and_spawn<HIST, false>(P, L, alive, has_ray, O, lane, a, best_t, best, s_hist, [&](uint32_t prim, Surface &S, uint32_t *prof) {
                     uint32_t mat;
