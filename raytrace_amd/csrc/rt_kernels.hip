@@ -361,112 +361,6 @@ __device__ __forceinline__ void box2_hit_fma(PlanePairs px, PlanePairs py, Plane
 
 enum { KIND_BRUTE_SPHERES = 0, KIND_BVH_SPHERES = 1, KIND_BVH_TRIANGLES = 2 };
 
-// Byte address of a __shared__ object inside the workgroup's LDS allocation (what a ds_* instruction takes).
-template <class T>
-__device__ __forceinline__ uint32_t lds_address(const T *p)
-{
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) T *)p;
-}
-
-// One traversal step of the LDS-resident sphere kernel, hand-scheduled (round 3).  The kernels are bound by the SIMD's
-// issue rate over ALL instructions, scalar ones included, and the compiler spends 76 instructions on this
-// step -- a third of them exec-mask arithmetic for the nested branches of the descend / push / pop logic -- where 62
-// do: every decision is a lane mask in an SGPR pair, every conditional block runs under `exec = mask` without skip
-// branches, and the two child refs are selected with v_cndmask instead of a four-way branch.  Same arithmetic and the same
-// order of stack and candidate entries as the C++ step below, so the image is bit-identical (the GPU suite and
-// tools/gpu_ab.py's CRCs compare them).
-//   node: ABSOLUTE LDS byte address of the lane's node (DONE = 0xFFFFFFFF); the child refs inside the staged nodes are
-//   absolute too (kernel prologue), so the step needs no base add.  Stack entries and candidates are 16 bits:
-//   stack_at0 / cand_at0 = LDS address of this thread's entry 0, entries are 2^SHIFT bytes apart ([entry][thread] layout).
-// Fixed temporaries v110..v127 and s84..s97 (named as clobbers): the 128-bit ds_read2_b64 results must be addressed by
-// halves, which compiler-chosen operands cannot be; the kernel stays at 128 VGPRs = 4 waves per SIMD.
-// exec is changed inside and restored before the end; LDS results are waited for inside.
-#define RT_PKFMA_T(dst, planes, op) "v_pk_fma_f32 " dst ", " planes ", " op ", " op " op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
-template <bool PERP, int SHIFT>
-__device__ __forceinline__ void step_lds_asm(uint32_t &node, uint32_t &sp, uint32_t &ncand, const RaySplat &R, float t_lo, float t_hi,
-                                             uint32_t stack_at0, uint32_t cand_at0)
-{
-    asm volatile(
-        "v_cmp_ne_u32_e32 vcc, -1, %[node]\n\t"
-        "s_and_saveexec_b64 s[84:85], vcc\n\t"                     // s[84:85] = exec at entry; exec = lanes with a node
-        "s_cbranch_execz .Lrt_step_end_%=\n\t"
-        "v_add_u32_e32 v124, %[node], %[ox]\n\t"
-        "v_add_u32_e32 v125, %[node], %[oy]\n\t"
-        "v_add_u32_e32 v126, %[node], %[oz]\n\t"
-        "ds_read2_b64 v[110:113], v124 offset1:1\n\t"              // x: {near0, near1, far0, far1}
-        "ds_read2_b64 v[114:117], v125 offset1:1\n\t"              // y
-        "ds_read2_b64 v[118:121], v126 offset1:1\n\t"              // z
-        "ds_read_b64 v[122:123], %[node] offset:72\n\t"            // child refs c0, c1
-        "s_waitcnt lgkmcnt(1)\n\t"
-        ".if %c[perp]\n\t"                                         // the second lower bound of an axis inside the cone (box2_hit_fma<true>)
-        RT_PKFMA_T("v[124:125]", "v[112:113]", "%[rex]") RT_PKFMA_T("v[110:111]", "v[110:111]", "%[rnx]") RT_PKFMA_T("v[112:113]", "v[112:113]", "%[rfx]")
-        "v_max_f32_e32 v110, v110, v124\n\t" "v_max_f32_e32 v111, v111, v125\n\t"
-        RT_PKFMA_T("v[124:125]", "v[116:117]", "%[rey]") RT_PKFMA_T("v[114:115]", "v[114:115]", "%[rny]") RT_PKFMA_T("v[116:117]", "v[116:117]", "%[rfy]")
-        "v_max_f32_e32 v114, v114, v124\n\t" "v_max_f32_e32 v115, v115, v125\n\t"
-        RT_PKFMA_T("v[124:125]", "v[120:121]", "%[rez]") RT_PKFMA_T("v[118:119]", "v[118:119]", "%[rnz]") RT_PKFMA_T("v[120:121]", "v[120:121]", "%[rfz]")
-        "v_max_f32_e32 v118, v118, v124\n\t" "v_max_f32_e32 v119, v119, v125\n\t"
-        ".else\n\t"
-        RT_PKFMA_T("v[110:111]", "v[110:111]", "%[rnx]") RT_PKFMA_T("v[114:115]", "v[114:115]", "%[rny]") RT_PKFMA_T("v[118:119]", "v[118:119]", "%[rnz]")
-        RT_PKFMA_T("v[112:113]", "v[112:113]", "%[rfx]") RT_PKFMA_T("v[116:117]", "v[116:117]", "%[rfy]") RT_PKFMA_T("v[120:121]", "v[120:121]", "%[rfz]")
-        ".endif\n\t"
-        "v_max_f32_e32 v118, v118, %[tlo]\n\t"
-        "v_max_f32_e32 v119, v119, %[tlo]\n\t"
-        "v_min_f32_e32 v120, v120, %[thi]\n\t"
-        "v_min_f32_e32 v121, v121, %[thi]\n\t"
-        "v_max3_f32 v118, v110, v114, v118\n\t"                    // entry distance of box 0
-        "v_max3_f32 v119, v111, v115, v119\n\t"                    //                      1
-        "v_min3_f32 v120, v112, v116, v120\n\t"                    // exit distance of box 0
-        "v_min3_f32 v121, v113, v117, v121\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_le_f32_e64 s[86:87], v118, v120\n\t"                // box 0 hit
-        "v_cmp_le_f32_e64 s[88:89], v119, v121\n\t"                // box 1 hit
-        "v_cmp_gt_i32_e64 s[90:91], 0, v122\n\t"                   // child 0 is a leaf (bit 31)
-        "v_cmp_gt_i32_e64 s[92:93], 0, v123\n\t"
-        "s_and_b64 s[94:95], s[86:87], s[90:91]\n\t"               // candidate 0
-        "s_and_b64 s[96:97], s[88:89], s[92:93]\n\t"               // candidate 1
-        "s_andn2_b64 s[86:87], s[86:87], s[90:91]\n\t"             // inner child 0 to visit
-        "s_andn2_b64 s[88:89], s[88:89], s[92:93]\n\t"             // inner child 1 to visit
-        "s_mov_b64 s[90:91], exec\n\t"                             // the stepping lanes
-        "s_mov_b64 exec, s[94:95]\n\t"
-        "v_lshl_add_u32 v127, %[nc], %[sh], %[cand0]\n\t"
-        "ds_write_b16 v127, v122\n\t"                              // low 16 bits = sphere index
-        "v_add_u32_e32 %[nc], 1, %[nc]\n\t"
-        "s_mov_b64 exec, s[96:97]\n\t"
-        "v_lshl_add_u32 v127, %[nc], %[sh], %[cand0]\n\t"
-        "ds_write_b16 v127, v123\n\t"
-        "v_add_u32_e32 %[nc], 1, %[nc]\n\t"
-        "s_mov_b64 exec, s[90:91]\n\t"
-        "v_cmp_le_f32_e32 vcc, v118, v119\n\t"                     // child 0 is the nearer one
-        "s_and_b64 s[92:93], s[86:87], s[88:89]\n\t"               // both inner children hit
-        "s_or_b64 s[94:95], s[86:87], s[88:89]\n\t"                // at least one
-        "v_cndmask_b32_e32 v124, v123, v122, vcc\n\t"              // nearer child
-        "v_cndmask_b32_e32 v125, v122, v123, vcc\n\t"              // farther child
-        "v_cndmask_b32_e64 v126, v123, v122, s[86:87]\n\t"         // the only one
-        "v_cndmask_b32_e64 %[node], v126, v124, s[92:93]\n\t"
-        "s_mov_b64 exec, s[92:93]\n\t"                             // both: stack the farther child
-        "v_lshl_add_u32 v127, %[sp], %[sh], %[stack0]\n\t"
-        "ds_write_b16 v127, v125\n\t"
-        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
-        "s_andn2_b64 exec, s[90:91], s[94:95]\n\t"                 // neither: pop, or finish on an empty stack
-        "v_mov_b32_e32 %[node], -1\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[sp]\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
-        "v_lshl_add_u32 v127, %[sp], %[sh], %[stack0]\n\t"
-        "ds_read_u16 %[node], v127\n\t"
-        "s_waitcnt lgkmcnt(0)\n"
-        ".Lrt_step_end_%=:\n\t"
-        "s_mov_b64 exec, s[84:85]"
-        : [node] "+v"(node), [sp] "+v"(sp), [nc] "+v"(ncand)
-        : [ox] "v"(R.ox), [oy] "v"(R.oy), [oz] "v"(R.oz), [rnx] "v"(R.nx), [rny] "v"(R.ny), [rnz] "v"(R.nz),
-          [rfx] "v"(R.fx), [rfy] "v"(R.fy), [rfz] "v"(R.fz), [rex] "v"(R.ex), [rey] "v"(R.ey), [rez] "v"(R.ez),
-          [tlo] "v"(t_lo), [thi] "v"(t_hi), [stack0] "v"(stack_at0), [cand0] "v"(cand_at0), [sh] "n"(SHIFT), [perp] "n"(PERP ? 1 : 0)
-        : "vcc", "memory",
-          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",
-          "v126", "v127", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
-}
-#undef RT_PKFMA_T
-
 struct Outputs {
     float              *accum;
     float              *partial;   // chunked mode: [n_chunks][P*3] partial sums, each cell written by one lane
@@ -801,8 +695,6 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
 {
     typedef typename std::conditional<LDSN, uint16_t, uint32_t>::type idx_t;
     constexpr int BLOCK = NT;
-    // LDS-resident sphere scenes step through step_lds_asm: nodes are then named by their absolute LDS address
-    constexpr bool ASM_STEP = LDSN && KIND == KIND_BVH_SPHERES && !PACKED && !WIDE && NT == 512;
     __shared__ uint32_t s_hist[HIST ? RT_HIST_WORDS + 2 * RT_PROF_BLOCKS : 1];
     __shared__ idx_t s_stack[STACK * BLOCK];          // [entry][thread]: a wave's accesses are conflict-free
     // Candidates (leaves whose box the ray's cone touches) wait for their exact test.
@@ -824,15 +716,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
     if (LDSN) {
         // the device nodes are already in traversal format (80 bytes, child refs = byte offsets): straight copy.
         // The 80-byte stride also spreads 16 lanes' reads of random nodes over all bank quads.
-        for (uint32_t k = threadIdx.x; k < n_nodes * LDS_NODE_STRIDE; k += NT) {
-            float4 v = bvh[k];
-            if (ASM_STEP && k % LDS_NODE_STRIDE == NODE_REFS_OFFSET / 16) {      // the float4 that ends in the two child refs
-                const uint32_t c0 = __float_as_uint(v.z), c1 = __float_as_uint(v.w), base = lds_address(s_scene);
-                if (!(c0 & LEAF_BIT)) v.z = __uint_as_float(c0 + base);      // inner refs: byte offset -> absolute LDS address
-                if (!(c1 & LEAF_BIT)) v.w = __uint_as_float(c1 + base);
-            }
-            s_scene[k] = v;
-        }
+        for (uint32_t k = threadIdx.x; k < n_nodes * LDS_NODE_STRIDE; k += NT) s_scene[k] = bvh[k];
         if (KIND == KIND_BVH_SPHERES)
             for (uint32_t k = threadIdx.x; k < P.n_prim; k += NT)
                 s_scene[n_nodes * LDS_NODE_STRIDE + k] = geom[k];
@@ -945,7 +829,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
                         RS.oy = 48u + (((__float_as_uint(L.d.y) >> 31) ^ 1u) << 4);
                         RS.oz = 96u + (((__float_as_uint(L.d.z) >> 31) ^ 1u) << 4);
                     }
-                    node = ASM_STEP ? lds_address(s_scene) : 0u; sp = 0; best_t = T_MAX; best = NOHIT;
+                    node = 0u; sp = 0; best_t = T_MAX; best = NOHIT;
                     if (SHARED_Q) s_wbest[tid] = NO_HIT_KEY;
                 }
             }
@@ -1034,10 +918,7 @@ __global__ __launch_bounds__(NT) void rt_trace_bvh_kernel(
             }
             bool push0 = false, push1 = false;
             uint32_t cand0 = 0, cand1 = 0;
-            if constexpr (ASM_STEP) {
-                if (HIST && node != DONE) c_lsteps += 1;
-                step_lds_asm<PERP, 10>(node, sp, ncand, RS, t_min_v, best_t, lds_address(&s_stack[tid]), lds_address(&s_cand[tid]));
-            } else if (node != DONE) {
+            if (node != DONE) {
                 if (HIST) c_lsteps += 1;
                 float tn0, tn1, tf0, tf1;
                 // node = byte offset (PACKED: node index)
