@@ -262,7 +262,9 @@ void rt_camera_basic(rt_camera *cam);
 void rt_camera_set_position(rt_camera *cam, const float lookfrom[3], const float lookat[3],
                             const float v_up[3], float vfov_deg, float aspect);
 /* Random_Scene, raytracer.zig:644-689 (sphere list; sfc64 stream seeded with `seed`, reference 0).
- * Writes up to cap spheres into the SoA arrays; returns the sphere count or RT_E_CAP. */
+ * Writes up to cap spheres into the SoA arrays; returns the sphere count or RT_E_CAP; half_size above
+ * RT_RANDOM_SCENE_MAX_HALF_SIZE (the reference uses 11) is RT_E_ARG. */
+#define RT_RANDOM_SCENE_MAX_HALF_SIZE 2048u
 int rt_random_scene(uint32_t half_size, uint64_t seed, uint32_t cap,
                     float *cx, float *cy, float *cz, float *radius, uint32_t *kind,
                     float *r, float *g, float *b, float *param);
@@ -271,7 +273,8 @@ int rt_two_sphere_scene(uint32_t cap, float *cx, float *cy, float *cz, float *ra
                         float *r, float *g, float *b, float *param);
 /* zmesh.Shape.initParametricSphere + scale + unweld as used at main.zig:128-143.  slices/stacks <= 0
  * selects the reference's per-radius tessellation.  v0/v1/v2 are [cap][3].  Returns the triangle
- * count or RT_E_CAP; call with cap = 0 to query the count. */
+ * count or RT_E_CAP; call with cap = 0 to query the count.  A request for 2^26 triangles or more (what
+ * rt_upload_scene refuses) is RT_E_ARG. */
 int rt_tessellate_spheres(const rt_spheres *spheres, int slices, int stacks, uint32_t cap,
                           float *v0, float *v1, float *v2, uint32_t *material);
 /* write_ppm_image, image.zig:18-37 (ASCII P3) */

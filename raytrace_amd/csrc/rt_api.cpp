@@ -184,6 +184,7 @@ int check_config(const rt_config *cfg)
     if ((uint64_t)cfg->nx * cfg->ny > 0x7FFFFFFFull / 3) return RT_E_ARG;   // pixel index and 3*pix fit 32 bits
     if (cfg->nx >= (1u << 24) || cfg->ny >= (1u << 24)) return RT_E_ARG;     // f32(i), f32(j) exact
     if (cfg->spp_end < cfg->spp_begin || cfg->spp_total == 0) return RT_E_ARG;
+    if (cfg->spp_end > 0x7FFFFFFFu) return RT_E_ARG;        // chunk bounds k * C + C are formed in 32 bits (advance_*)
     if (cfg->max_depth > 1000000u) return RT_E_ARG;
     if (cfg->spp_chunk != 0 && cfg->spp_chunk != RT_SPP_CHUNK_AUTO) {
         const uint64_t nc = ((uint64_t)cfg->spp_end + cfg->spp_chunk - 1) / cfg->spp_chunk - cfg->spp_begin / cfg->spp_chunk;
@@ -1127,7 +1128,7 @@ void rt_camera_basic(rt_camera *cam)
 void rt_camera_set_position(rt_camera *cam, const float lookfrom[3], const float lookat[3], const float v_up[3],
                             float vfov_deg, float aspect)
 {
-    if (!cam) return;
+    if (!cam || !lookfrom || !lookat || !v_up) return;
     rt::MovableCamera c;
     c.SetPosition({ lookfrom[0], lookfrom[1], lookfrom[2] }, { lookat[0], lookat[1], lookat[2] },
                   { v_up[0], v_up[1], v_up[2] }, vfov_deg, aspect);
@@ -1138,6 +1139,8 @@ int rt_random_scene(uint32_t half_size, uint64_t seed, uint32_t cap, float *cx, 
                     uint32_t *kind, float *r, float *g, float *b, float *param)
 {
     return guarded([&]() -> int {
+        // (2 half_size)^2 grid cells are visited whatever `cap` says: bound the work and the memory of a bad argument
+        if (half_size > RT_RANDOM_SCENE_MAX_HALF_SIZE) return RT_E_ARG;
         rt::RndGen rng = rt::RndGen::init(seed);
         const rt::Hittable world = rt::Random_Scene(half_size, rng);
         if (world.objects.size() > cap) return RT_E_CAP;
@@ -1164,6 +1167,17 @@ int rt_tessellate_spheres(const rt_spheres *sph, int slices, int stacks, uint32_
 {
     return guarded([&]() -> int {
         if (!sph || !sph->cx || !sph->cy || !sph->cz || !sph->radius) return RT_E_ARG;
+        // at most 2 * slices * stacks triangles per sphere, and rt_upload_scene takes fewer than 2^26: a larger request is
+        // refused before any memory is touched
+        {
+            uint64_t worst = 0;
+            for (uint32_t k = 0; k < sph->n; ++k) {
+                uint64_t sl = slices > 0 && stacks > 0 ? (uint64_t)slices : (sph->radius[k] > 50 ? 150u : sph->radius[k] < 1.0f ? 20u : 30u);
+                uint64_t st = slices > 0 && stacks > 0 ? (uint64_t)stacks : sl;
+                worst += 2 * sl * st;
+                if (worst >= (1ull << 26)) return RT_E_ARG;
+            }
+        }
         std::vector<rt::Sphere> objs(sph->n);
         for (uint32_t k = 0; k < sph->n; ++k) {
             objs[k].center = { sph->cx[k], sph->cy[k], sph->cz[k] };

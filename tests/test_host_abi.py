@@ -171,3 +171,25 @@ def test_config_defaults_are_the_reference_constants():
     cfg = R.make_config(1200, 675, 25)
     assert cfg.max_depth == 16 and abs(cfg.t_min - 0.001) < 1e-9 and cfg.row_offset_q3 == 1
     assert (cfg.spp_begin, cfg.spp_end, cfg.spp_total) == (0, 25, 25)
+
+
+def test_host_mirrors_refuse_runaway_arguments():
+    """Arguments that would make a host-side mirror allocate without bound come back as RT_E_ARG at once
+    (rt_random_scene visits (2 half_size)^2 cells whatever `cap` is; rt_tessellate_spheres makes 2 slices stacks
+    triangles per sphere), and a NULL vector leaves rt_camera_set_position's camera untouched."""
+    L = _lib.load()
+    s = R.Spheres.empty(4)
+    assert L.rt_random_scene(2049, 0, 4, *s._out_ptrs()) == _lib.RT_E_ARG
+    assert L.rt_random_scene(0xFFFFFFFF, 0, 4, *s._out_ptrs()) == _lib.RT_E_ARG
+    two = R.Two_Sphere_Scene()
+    sv = two.view()
+    assert L.rt_tessellate_spheres(C.byref(sv), 100000, 100000, 0, None, None, None, None) == _lib.RT_E_ARG
+    assert L.rt_tessellate_spheres(C.byref(sv), 4100, 4100, 0, None, None, None, None) == _lib.RT_E_ARG   # 2 x 33.6 M >= 2^26
+    assert L.rt_tessellate_spheres(C.byref(sv), 8, 8, 0, None, None, None, None) > 0
+    cam = R.BasicCamera()
+    before = bytes(cam._c)
+    a3 = C.c_float * 3
+    raw = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float)(("rt_camera_set_position", L))
+    at, up = a3(0, 0, 0), a3(0, 1, 0)
+    raw(C.addressof(cam._c), None, C.addressof(at), C.addressof(up), 20.0, 1.5)
+    assert bytes(cam._c) == before
