@@ -6,15 +6,59 @@
 //
 // num_samples is the total per pixel (the reference renders num_samples on each CPU thread, raytracer.zig:594-608).
 // With n_gpus > 1 the samples are split over that many GPUs (rt_render_multi, the role of the thread fan-out).
+//
+//     rt_main trace [num_samples [n_passes [out.ppm [nx ny [px py pz fx fy fz]]]]]
+//
+// the GUI's "Trace" button without the window (src/main.zig:307-318, 342-345): camera set the way start_trace sets it from
+// the fly camera at (px,py,pz) looking along (fx,fy,fz) -- defaults: DemoState's initial values, main.zig:65-69 --, the
+// render in n_passes polling passes (rt::TraceJob), the picture so far written to out.ppm after every pass (what the window
+// would show), the finished Scene.ppm at the end.  Defaults: 25 samples (main.zig:344), 5 passes, Scene.ppm, 1200 x 675.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "raytracer.hpp"
 
+static int trace_button(int argc, char **argv)
+{
+    const int num_samples = argc > 2 ? std::atoi(argv[2]) : 200 / 8;                                  // main.zig:344
+    const int n_passes = argc > 3 ? std::atoi(argv[3]) : 5;
+    const char *fname = argc > 4 ? argv[4] : "Scene.ppm";
+    const long nx = argc > 6 ? std::atol(argv[5]) : 1200, ny = argc > 6 ? std::atol(argv[6]) : 675;
+    float v[6] = { 0.0f, 4.0f, -4.0f, 0.0f, 0.0f, 1.0f };                                             // main.zig:66-67
+    if (argc > 12) for (int k = 0; k < 6; ++k) v[k] = (float)std::atof(argv[7 + k]);
+    if (num_samples < 1 || num_samples > 65535 || n_passes < 1 || nx < 1 || ny < 1) {
+        std::fprintf(stderr, "usage: %s trace [num_samples [n_passes [out.ppm [nx ny [px py pz fx fy fz]]]]]\n", argv[0]);
+        return 2;
+    }
+    rt::RndGen rng = rt::RndGen::init(0);                                                            // main.zig:570
+    const rt::Hittable World = rt::Random_Scene(11, rng);                                            // main.zig:578
+    rt_ctx *ctx = nullptr;
+    int rc = rt_create(0, &ctx);
+    if (rc != RT_OK) { std::fprintf(stderr, "rt_create: %s\n", rt_strerror(rc)); return 1; }
+    rt::TraceJob job;
+    rc = job.begin(ctx, World, { v[0], v[1], v[2] }, { v[3], v[4], v[5] }, (uint16_t)num_samples, (uint32_t)n_passes,
+                   rt::shape_s{ (size_t)ny, (size_t)nx });
+    while (rc == RT_OK && job.active) {                 // the window's frame loop: one pass per frame
+        rc = job.poll();
+        if (rc == RT_OK || rc == RT_PROGRESS_MORE) {
+            std::printf("pass: %u of %d samples, %llu rays so far\n", job.spp_done, num_samples, (unsigned long long)job.stats.rays);
+            const int wrc = job.finish(fname);          // the picture so far
+            rc = wrc != RT_OK ? wrc : RT_OK;
+        }
+    }
+    if (rc != RT_OK) { std::fprintf(stderr, "trace failed: %s (hip %d)\n", rt_strerror(rc), rt_last_hip_error(ctx)); rt_destroy(ctx); return 1; }
+    std::printf("Traced %u samples per pixel in %.2f ms of kernels: %llu rays\n", job.spp_done, job.stats.kernel_ms,
+                (unsigned long long)job.stats.rays);
+    rt_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::strcmp(argv[1], "trace") == 0) return trace_button(argc, argv);
     const size_t nx = argc > 1 ? (size_t)std::atol(argv[1]) : 1200, ny = argc > 2 ? (size_t)std::atol(argv[2]) : 675;
     const uint16_t num_samples = argc > 3 ? (uint16_t)std::atoi(argv[3]) : 1;                       // raytracer.zig:718
     const char *fname = argc > 4 ? argv[4] : "Scene.ppm";

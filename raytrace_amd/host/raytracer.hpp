@@ -213,4 +213,59 @@ inline int render_and_write(rt_ctx *ctx, const std::string &fname, uint16_t num_
     return rt_render_and_write(ctx, fname.c_str(), &c, &cfg, stats);
 }
 
+// ---- the GUI's "Trace" button without the window (main.zig:307-318, 342-345) ---------------------------------------
+// The reference's start_trace sets the camera from the GUI's fly camera -- SetPosition(cam_pos, cam_forward,
+// cam_pos + (0,1,0), 45, 1200/675): `lookat` receives the FORWARD VECTOR and v_up a point above the camera (quirk Q9,
+// kept) -- and then blocks the UI thread inside render_and_write until Scene.ppm is written.  TraceJob is the same call
+// in polling form (the C++ twin of zig/hip_backend.zig's TraceJob): begin() = the body of start_trace up to the render,
+// poll() = one pass, called once per frame where compute.onCompute was meant to go (main.zig:620-626) -- rgb8 then holds
+// the picture so far --, finish() = the file.
+struct TraceJob {
+    rt_ctx              *ctx = nullptr;
+    std::vector<uint8_t> rgb8;
+    shape_s              shape{ 675, 1200 };                    // main.zig:312-313
+    uint32_t             spp_done = 0;
+    bool                 active = false;
+    rt_stats             stats{};
+
+    int begin(rt_ctx *c, const Hittable &world, vec_type cam_pos, vec_type cam_forward, uint16_t num_samples, uint32_t n_passes,
+              shape_s shp = shape_s{ 675, 1200 }) {
+        ctx = c; shape = shp; spp_done = 0; active = false;
+        const vec_type cam_up{ cam_pos.x, cam_pos.y + 1.0f, cam_pos.z };                             // main.zig:310
+        cam.SetPosition(cam_pos, cam_forward, cam_up, 45.0f, (float)shape.nx / (float)shape.ny);      // main.zig:314-315
+        SphereSoA soa(world.objects);
+        const rt_spheres view = soa.view();
+        int rc = rt_upload_scene(ctx, &view, nullptr, nullptr);
+        if (rc != RT_OK) return rc;
+        rt_config cfg{};
+        cfg.nx = (uint32_t)shape.nx; cfg.ny = (uint32_t)shape.ny;
+        cfg.spp_begin = 0; cfg.spp_end = num_samples; cfg.spp_total = num_samples;
+        cfg.max_depth = 16; cfg.t_min = 0.001f; cfg.seed = 1; cfg.row_offset_q3 = 1; cfg.spp_chunk = 0;
+        const rt_camera abi = cam.to_abi();
+        rgb8.assign(shape.nx * shape.ny * 3, 0);
+        rc = rt_progressive_begin(ctx, &abi, &cfg, n_passes);
+        active = rc == RT_OK;
+        return rc;
+    }
+    // one pass; RT_PROGRESS_MORE while passes remain, RT_OK after the last one, an error code otherwise
+    int poll() {
+        if (!active) return RT_E_STATE;
+        const int rc = rt_progressive_step(ctx, rgb8.data(), nullptr, &spp_done, &stats);
+        active = rc == RT_PROGRESS_MORE;
+        return rc;
+    }
+    int finish(const std::string &fname) const {                                                     // main.zig:317 "Scene.ppm"
+        return rt_write_ppm(fname.c_str(), rgb8.data(), (uint32_t)shape.nx, (uint32_t)shape.ny);
+    }
+};
+
+// start_trace (main.zig:307-318) as the reference has it: blocking, one file at the end.
+inline int start_trace(rt_ctx *ctx, const Hittable &world, vec_type cam_pos, vec_type cam_forward, uint16_t num_samples,
+                       const std::string &fname = "Scene.ppm", shape_s shape = shape_s{ 675, 1200 }) {
+    TraceJob job;
+    int rc = job.begin(ctx, world, cam_pos, cam_forward, num_samples, 1, shape);
+    while (rc == RT_OK && job.active) { rc = job.poll(); if (rc == RT_PROGRESS_MORE) rc = RT_OK; }
+    return rc == RT_OK ? job.finish(fname) : rc;
+}
+
 }  // namespace rt

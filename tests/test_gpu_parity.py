@@ -941,6 +941,39 @@ def test_progressive_render_converges_to_rt_render(gpu_ctx):
     assert [d for d, *_ in gpu_ctx.render_progressive(cam, R.make_config(nx, ny, 3), 10)] == [1, 2, 3]
 
 
+def test_trace_button_without_the_window(tmp_path):
+    """rt_main trace: the GUI's Trace button (main.zig:307-318, 342-345) through rt::TraceJob -- camera set as start_trace
+    sets it from the fly camera (quirk Q9: the forward vector as look-at, pos + (0,1,0) as up, vfov 45), the render in
+    polling passes with the picture so far on disk after each.  The finished file is the ORACLE's image for that camera
+    (per-pixel bytes within the PSNR bar, ray total exact), and the pass log counts the samples up."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytrace_amd", "host", "rt_main")
+    assert os.path.exists(exe), "build it first: make -C raytrace_amd/csrc (__graft_entry__.build())"
+    nx, ny, spp, passes = 160, 90, 6, 3
+    pos, fwd = (0.0, 4.0, -4.0), (0.0, -0.45399049973954675, 0.8910065241883679)     # DemoState's camera after one update(): pitch 0.15 pi
+    f = str(tmp_path / "Scene.ppm")
+    out = subprocess.run([exe, "trace", str(spp), str(passes), f, str(nx), str(ny)] + [repr(float(x)) for x in pos + fwd],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert [l.split(":")[1].split()[0] for l in out.stdout.splitlines() if l.startswith("pass:")] == ["2", "4", "6"]
+    assert open(f).read().split("\n")[:3] == ["P3", "%d %d" % (nx, ny), "255"]
+    a = np.loadtxt(f, skiprows=3, dtype=np.int64).reshape(-1, 3)
+    up = (pos[0], pos[1] + 1.0, pos[2])
+    aspect = float(np.float32(nx) / np.float32(ny))
+    ocam = O.camera_set_position(tuple(np.float32(pos)), tuple(np.float32(fwd)), up, 45.0, aspect)
+    w = O.World(spheres=O.random_scene(11, 0))
+    _, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, spp_chunk=spp // passes))
+    assert psnr_u8(a, o8) >= MIN_PSNR
+    assert "%d rays" % cnt["rays"] in out.stdout.splitlines()[-1]
+    # the library path with the same camera and chunking: byte-equal
+    with R.Context(0) as ctx:
+        ctx.upload_scene(R.Random_Scene(11, 0))
+        cam = R.MovableCamera().SetPosition(tuple(np.float32(pos)), tuple(np.float32(fwd)), up, 45.0, aspect)
+        res = ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=spp // passes))
+    assert np.array_equal(a, res.rgb8.astype(np.int64))
+    assert subprocess.run([exe, "trace", "0"], capture_output=True, timeout=60).returncode == 2
+
+
 def test_render_and_write_ppm(gpu_ctx, tmp_path):
     """render_and_write (raytracer.zig:580-633) -> the same P3 file the oracle writes for its image."""
     nx, ny, spp = 48, 27, 4
