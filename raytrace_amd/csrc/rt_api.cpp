@@ -202,7 +202,7 @@ int check_config(const rt_config *cfg)
 
 // max_planes bounds the number of partial-sum planes (0 = no bound): RT_SPP_CHUNK_AUTO then picks a chunk size that
 // needs no more than that many; an explicit spp_chunk is taken as given (the caller checks p.n_chunks).
-void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, bool triangles,
+void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uint32_t n_prim, TraceKernel kernel,
                  const rt_tuning &tune, uint64_t max_planes = 0)
 {
     std::memset(&p, 0, sizeof p);
@@ -226,14 +226,21 @@ void fill_params(TraceParams &p, const rt_camera *cam, const rt_config *cfg, uin
     uint32_t chunk = cfg->spp_chunk;
     const uint32_t n_spp = cfg->spp_end - cfg->spp_begin;
     const uint64_t pixel_items = (uint64_t)p.tiles_x * tiles_y * 64u;
+    const bool triangles = kernel == RT_K_BVH_TRIANGLES;
     if (chunk == RT_SPP_CHUNK_AUTO) {
         // enough items to keep the tail short (~80 per lane of a full chip; measured on C3: 10 planes run as fast
-        // as 17 or 25 and write less), chunks of at least 4 samples
+        // as 17 or 25 and write less).  How small a chunk may get depends on what an item costs against its fixed
+        // overhead (dequeue, write-out, one shading pass with few lanes), measured on MI355X in round 3:
+        // the brute-force kernel's cheap rays want at least 8 samples per item, the sphere tree 2 -- 1 while that
+        // still leaves fewer than 16 items per lane --, the triangle tree 1.  (Until round 3 the floor was 4 for all:
+        // small launches then had less than one item per lane -- C1 ran 3x, a 400 x 225 mesh 3.5x slower.)
         const uint64_t want_items = 64ull * 256 * 1280;
+        uint32_t min_chunk = kernel == RT_K_BRUTE_SPHERES ? 8u : (triangles ? 1u : 2u);
+        if (kernel == RT_K_BVH_SPHERES && pixel_items * ((n_spp + 1) / 2) < 16ull * (64 * 256 * 16)) min_chunk = 1u;   // 262 144 resident lanes
         chunk = 0;
-        if (n_spp >= 8 && pixel_items < want_items) {
+        if (n_spp >= 2 * min_chunk && pixel_items < want_items) {
             uint64_t nc = (want_items + pixel_items - 1) / pixel_items;
-            if (nc > n_spp / 4) nc = n_spp / 4;
+            if (nc > n_spp / min_chunk) nc = n_spp / min_chunk;
             if (nc > 64) nc = 64;
             if (max_planes != 0 && nc > max_planes) nc = max_planes;
             if (nc > 1) chunk = (uint32_t)((n_spp + nc - 1) / nc);
@@ -295,7 +302,7 @@ int enqueue_trace(rt_ctx *ctx, const rt_camera *cam, const rt_config *cfg, float
     const size_t plane = (size_t)cfg->nx * cfg->ny * 3;
     uint64_t max_planes = 0;     // fixed scratch: as many planes as fit, at least "one" (= no chunking)
     if (fixed) { max_planes = fixed->partial_cap / plane; if (max_planes < 1) max_planes = 1; }
-    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, ctx->n_tri != 0, ctx->tuning, max_planes);
+    fill_params(p, cam, cfg, ctx->n_tri ? ctx->n_tri : ctx->n_sph, pick_kernel(ctx), ctx->tuning, max_planes);
     if (fixed && p.n_chunks > 1 && (uint64_t)plane * p.n_chunks > fixed->partial_cap) return RT_E_CAP;
     uint32_t *const d_queue = fixed ? fixed->queue : ctx->d_queue;
     unsigned long long *const d_stats = fixed ? fixed->stats : ctx->d_stats;
