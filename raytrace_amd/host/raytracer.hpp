@@ -240,7 +240,7 @@ struct TraceJob {
         rt_config cfg{};
         cfg.nx = (uint32_t)shape.nx; cfg.ny = (uint32_t)shape.ny;
         cfg.spp_begin = 0; cfg.spp_end = num_samples; cfg.spp_total = num_samples;
-        cfg.max_depth = 16; cfg.t_min = 0.001f; cfg.seed = 1; cfg.row_offset_q3 = 1; cfg.spp_chunk = 0;
+        cfg.max_depth = 16; cfg.t_min = 0.001f; cfg.seed = 1; cfg.row_offset_q3 = 1; cfg.spp_chunk = RT_SPP_CHUNK_AUTO;   // (as the Zig twin: short passes need the small items)
         const rt_camera abi = cam.to_abi();
         rgb8.assign(shape.nx * shape.ny * 3, 0);
         rc = rt_progressive_begin(ctx, &abi, &cfg, n_passes);

@@ -965,12 +965,12 @@ def test_trace_button_without_the_window(tmp_path):
     _, o8, _, cnt = O.render_counter(w, ocam, O.make_config(nx, ny, spp, spp_chunk=spp // passes))
     assert psnr_u8(a, o8) >= MIN_PSNR
     assert "%d rays" % cnt["rays"] in out.stdout.splitlines()[-1]
-    # the library path with the same camera and chunking: byte-equal
+    # the library path with the same camera: the same picture up to the f32 sum order RT_SPP_CHUNK_AUTO leaves open inside a pass
     with R.Context(0) as ctx:
         ctx.upload_scene(R.Random_Scene(11, 0))
         cam = R.MovableCamera().SetPosition(tuple(np.float32(pos)), tuple(np.float32(fwd)), up, 45.0, aspect)
         res = ctx.render(cam, R.make_config(nx, ny, spp, spp_chunk=spp // passes))
-    assert np.array_equal(a, res.rgb8.astype(np.int64))
+    assert np.abs(a - res.rgb8.astype(np.int64)).max() <= 1 and psnr_u8(a, res.rgb8) >= MIN_PSNR
     assert subprocess.run([exe, "trace", "0"], capture_output=True, timeout=60).returncode == 2
 
 
