@@ -164,6 +164,27 @@ def test_lds_and_global_scene_variants_agree(gpu_ctx):
     assert np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32))
 
 
+def test_largest_lds_resident_sphere_scene(gpu_ctx):
+    """Random_Scene(14): 514 spheres, 49 KB of nodes and sphere records -- inside the 55 KB that sphere scenes may take of
+    a workgroup's LDS share (more than the 64 KB a kernel gets by default together with the stacks: the launch raises
+    the limit).  Against the oracle, and bit for bit against the global-memory variant."""
+    nx, ny, spp = 128, 72, 4
+    s = R.Random_Scene(14, 0)
+    assert 40 * 1024 < (len(s) - 1) * 80 + len(s) * 16 <= 55 * 1024
+    cam, ocam = R.book_camera(nx, ny), O.book_camera(nx, ny)
+    gpu_ctx.set_flags(0)
+    gpu_ctx.upload_scene(s)
+    a = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    oa, o8, orc, cnt = O.render_counter(O.World(spheres=spheres_to_oracle(s)), ocam, O.make_config(nx, ny, spp))
+    _compare(a, oa, o8, orc, cnt)
+    try:
+        gpu_ctx.set_tuning(force_global_scene=1)
+        b = gpu_ctx.render(cam, R.make_config(nx, ny, spp), want_raycount=True)
+    finally:
+        gpu_ctx.set_tuning()
+    assert np.array_equal(a.raycount, b.raycount) and np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32))
+
+
 def test_kernel_flavours_are_bit_identical(gpu_ctx):
     """The BVH only culls; the exact tests and the shading are the brute-force kernel's, so the two
     flavours must produce the same bits."""
